@@ -1,0 +1,118 @@
+/* rgs_hip.h -- C ABI of the MI355X batched robo-game-sim stepper (librgs_hip.so).
+ *
+ * Drop-in boundary for the reference's GameSim hot path.  The reference exposes
+ * the path to Python through pybind11 (src/RoboGamePy.cpp:11-25, class GameSim:
+ * reset / undecided / run, declared in include/GameSim.h:21-27).  This library
+ * is what a replacement binding links instead of src/GameSim.cpp: plain
+ * pointers and sizes, int status codes, no exceptions, caller-owned buffers.
+ * One handle = one batch of independent arenas resident on one GPU.  Calls on a
+ * handle must be serialised by the caller (the reference is single-threaded too).
+ *
+ * Array layouts (all IEEE binary64, arena index fastest = "SoA over arenas"):
+ *   state     [S][B]        S = 2 + 4*(2n+1); rows in include/SimState.h:14-23
+ *                           order: TAS, TBS, PK(px,py,vx,vy), A1(4)..An(4), B1(4)..Bn(4)
+ *   controls  [P][2][B]     P = 2n players in disc order A1..An,B1..Bn
+ *   x0_ball   [4][B]        or a single [4] broadcast to every arena
+ *   damage    [P*P][B]      row-major (aggressor, victim), include/SimState.h:33-38
+ *   time      [B]           the reference's t_ (src/GameSim.cpp:158)
+ */
+#ifndef RGS_HIP_H
+#define RGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rgs_sim rgs_sim;
+
+enum {
+  RGS_OK = 0,
+  RGS_ERR_ARG = -1,          /* bad argument (null, range, n_per_team not in 1..7) */
+  RGS_ERR_HIP = -2,          /* a HIP runtime call failed; see rgs_last_error() */
+  RGS_ERR_UNSUPPORTED = -3,  /* feature outside this build (noise > 0) */
+  RGS_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
+};
+
+/* Stepper variants (rgs_set_variant).  All give bit-identical results. */
+enum {
+  RGS_VARIANT_AUTO = 0,
+  RGS_VARIANT_WAVE = 1,      /* one wavefront owns one arena, grid in LDS */
+  RGS_VARIANT_HYBRID = 2     /* lane-per-arena streaming pass + LDS event pass */
+};
+
+/* Human-readable text for the most recent failure on this thread. */
+const char *rgs_last_error(void);
+
+/* Number of doubles in one arena's state vector (SimState::SIZE, include/SimState.h:22; 22 at n=2). */
+int rgs_state_size(int n_per_team);
+
+/* GameSim::GameSim (src/GameSim.cpp:3-17) for n_arenas independent arenas on `device_id`.
+ * The arenas start as after reset() with the C++ default arguments (src/GameSim.cpp:21-25). */
+int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out);
+int rgs_destroy(rgs_sim *sim);
+
+/* GameSim::reset (include/GameSim.h:21-24, src/GameSim.cpp:21-55).  log/logname are host-side
+ * concerns and live in the Python layer.  x0_ball_host: [4] if !x0_batched else [4][B].
+ * noise != 0 returns RGS_ERR_UNSUPPORTED.  `seed` is recorded only (with
+ * noise == 0 the reference's seed has no effect on the physics). */
+int rgs_reset(rgs_sim *sim, double dt, int winning_score, const double *x0_ball_host, int x0_batched,
+              double noise, int seed, double tau_puck, double tau_player, double player_mass,
+              double puck_mass);
+
+/* GameSim::run (include/GameSim.h:26-27, src/GameSim.cpp:118-124) on every arena: arenas that are
+ * still undecided advance one step, decided arenas are left untouched.  controls_host [P][2][B]. */
+int rgs_step(rgs_sim *sim, const double *controls_host);
+
+/* Same, controls already on the device: n_steps consecutive steps, step k reading
+ * controls_dev + k*step_stride (doubles; stride 0 = hold one set).  Asynchronous on the
+ * handle's stream; rgs_sync() or any rgs_get_* waits for it. */
+int rgs_step_device(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps);
+
+int rgs_sync(rgs_sim *sim);
+
+/* The value GameSim::run / reset return (state_.vector(), src/GameSim.cpp:54,123), for all arenas. */
+int rgs_get_state(rgs_sim *sim, double *state_host);
+/* GameSim::undecided (src/GameSim.cpp:57-60) per arena: 1 = still running. */
+int rgs_undecided(rgs_sim *sim, uint8_t *out_host);
+/* SimState::damage (include/SimState.h:33), not reachable through the reference binding. */
+int rgs_get_damage(rgs_sim *sim, double *damage_host);
+int rgs_get_time(rgs_sim *sim, double *time_host);
+
+/* Extension: overwrite state and time of every arena; damage is zeroed. */
+int rgs_set_state(rgs_sim *sim, const double *state_host, const double *time_host);
+
+/* Zero-copy access for device-side callers (torch tensors, RCCL all-gather). */
+int rgs_state_device_ptr(rgs_sim *sim, double **out_dev);   /* [S][B] */
+int rgs_copy_state_to_device(rgs_sim *sim, double *dst_dev); /* async on the handle's stream */
+int rgs_stream(rgs_sim *sim, void **out_hip_stream);
+
+/* Device memory helpers so a ctypes host can own control tables without another runtime. */
+int rgs_device_alloc(rgs_sim *sim, int64_t n_doubles, double **out_dev);
+int rgs_device_free(rgs_sim *sim, double *dev);
+int rgs_device_upload(rgs_sim *sim, double *dst_dev, const double *src_host, int64_t n_doubles);
+int rgs_device_download(rgs_sim *sim, double *dst_host, const double *src_dev, int64_t n_doubles);
+
+/* HIP-event timer on the handle's stream: start ... launches ... stop -> milliseconds. */
+int rgs_timer_start(rgs_sim *sim);
+int rgs_timer_stop(rgs_sim *sim, float *ms_out);
+
+/* Run-time counters summed over arenas since the last reset:
+ * out[0] executed arena-steps, [1] events resolved, [2] steps ended by the 50-iteration cap
+ * (include/GameSim.h:7), [3] base index past the grid (reference: out-of-bounds write; clamped here),
+ * [4] puck events skipped after a goal (src/GameSim.cpp:230-231), [5] arena-steps that took the
+ * event pass, [6..7] reserved. */
+int rgs_get_counters(rgs_sim *sim, int64_t *out8);
+
+int rgs_set_variant(rgs_sim *sim, int variant);
+
+/* Device arithmetic self-test: computes a[i]/b[i] and sqrt(a[i]) on the GPU with the same
+ * code paths the stepper uses, for comparison with the host's IEEE results. */
+int rgs_selftest_math(int device_id, const double *a_host, const double *b_host, int64_t n,
+                      double *quot_host, double *sqrt_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGS_HIP_H */

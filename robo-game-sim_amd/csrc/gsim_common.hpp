@@ -1,0 +1,102 @@
+// gsim_common.hpp -- shared device-side definitions of the batched stepper.
+//
+// Arithmetic contract: IEEE binary64, one rounding per operation, in the
+// association order of the reference (src/GameSim.cpp); the translation unit is
+// compiled with -ffp-contract=off so hipcc forms no FMA from a*b+c.  Explicit
+// __builtin_fma calls appear only inside div_by() (a correctly rounded quotient).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsim {
+
+constexpr int kGrid = 50;          // sub-steps per step        include/GameSim.h:6
+constexpr int kLoopCap = 50;       // event-loop iteration cap  include/GameSim.h:7
+constexpr int kCols = kGrid + 1;
+
+// Arena geometry, src/GameSim.cpp:5-9.  Compile-time: the reference never changes them.
+constexpr double kX = 10.0, kY = 5.0, kRPlayer = 0.2, kRPuck = 0.175, kGoalH = 1.0;
+
+enum Kind : int { UP = 0, DOWN = 1, RIGHT = 2, LEFT = 3, PAIR = 4 };  // include/Collision.h:5
+
+enum Counter : int {
+  CNT_RESOLVED = 0,       // events carried out
+  CNT_CAP_HITS = 1,       // steps ended by the 50-iteration cap
+  CNT_BASE_OVERFLOW = 2,  // base index past the grid (clamped)
+  CNT_SKIPPED = 3,        // puck events dropped after a goal, cpp:230-231
+  CNT_EVENT_STEPS = 4,    // arena-steps that entered the event pass
+  CNT_N = 8
+};
+
+// Everything one launch needs.  Arrays are SoA with the arena index fastest.
+struct StepArgs {
+  double dt, dt_col;                 // cpp:27-28
+  double tau_player, tau_puck;       // cpp:43-44
+  double m_player, m_puck;           // cpp:45-46
+  double win;                        // winning_score_ as a double (scores are doubles, SimState.h:25)
+  long long B;                       // arenas
+  double *state;                     // [S][B]
+  double *tcur;                      // [B]    t_
+  double *damage;                    // [P*P][B]
+  const double *ctl;                 // [P][2][B] of step 0
+  long long ctl_stride;              // doubles between consecutive steps' controls
+  int n_steps;
+  unsigned long long *counters;      // [CNT_N]
+  int *queue;                        // hybrid: [B] arena indices needing the event pass
+  int *queue_count;                  // hybrid: [n_steps] or [1]
+};
+
+// State-vector row of disc e's first component (include/SimState.h:14-23; players after the puck).
+template <int N>
+__device__ __forceinline__ int state_row(int e) {
+  return e == 2 * N ? 2 : 6 + 4 * e;
+}
+
+// a / b, correctly rounded (hipcc lowers fp64 '/' to the div_scale/rcp/fma/div_fmas/div_fixup
+// sequence, which is IEEE-exact; checked on the device by rgs_selftest_math).
+__device__ __forceinline__ double div_ieee(double a, double b) { return a / b; }
+__device__ __forceinline__ double sqrt_ieee(double a) { return __builtin_sqrt(a); }
+
+// max(0, x) as the reference's fmax(0.0, x) (cpp:388,...): NaN -> 0.
+__device__ __forceinline__ double max0(double x) { return x > 0.0 ? x : 0.0; }
+
+// One axis of one disc: position and velocity along x or y.  The reference's
+// 4-vector RK4 (cpp:70-116) never couples the axes, so a (p, v) pair carries a
+// complete, independent chain.
+struct Chain {
+  double p, v;
+};
+
+// RK4_player / RK4_puck (src/GameSim.cpp:70-88, 98-116) restricted to one axis.
+//   f(x) = (v, (u - coef*v)/tau): coef = 1 for players (cpp:66-67 with sigma = 0;
+//   1.0*v is exact), 0.2 for the puck (cpp:94-95, whose u is always 0).
+// The position rows of x2..x4 never feed f, so only their velocity rows exist here.
+__device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double tau, double h) {
+  const double half = h / 2.0;
+  const double k1p = x.v;
+  const double k1v = div_ieee(u - coef * x.v, tau);
+  const double x2v = x.v + k1v * half;
+  const double k2p = x2v;
+  const double k2v = div_ieee(u - coef * x2v, tau);
+  const double x3v = x.v + k2v * half;
+  const double k3p = x3v;
+  const double k3v = div_ieee(u - coef * x3v, tau);
+  const double x4v = x.v + k3v * h;
+  const double k4p = x4v;
+  const double k4v = div_ieee(u - coef * x4v, tau);
+  const double w = h / 6.0;
+  Chain r;
+  r.p = x.p + (((k1p + k2p * 2.0) + k3p * 2.0) + k4p) * w;   // cpp:87
+  r.v = x.v + (((k1v + k2v * 2.0) + k3v * 2.0) + k4v) * w;
+  return r;
+}
+
+// Orders LDS traffic between lanes of ONE wavefront: LDS operations of a wave
+// execute in order, so only the compiler has to be kept from moving them.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace gsim

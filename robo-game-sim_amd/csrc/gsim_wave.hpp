@@ -1,0 +1,383 @@
+// gsim_wave.hpp -- one lane-group (GW = 16/32/64 lanes of one wavefront) owns one arena.
+//
+// The whole step of the reference (GameSim::updateSim, src/GameSim.cpp:126-171) for one
+// arena, with the 51-column state grid (state_grid_, include/GameSim.h:46) staged in LDS:
+//
+//   fill      lanes (disc, axis) integrate their own RK4 chain down the 50 sub-steps
+//             (populateStateGrid, cpp:173-217) and write the columns to LDS;
+//   scan      lane <-> grid column: every lane runs the wall / disc-pair overlap tests of
+//             one column (insertCollisions, cpp:360-511); a ballot over the group picks
+//             the first column with an admissible event;
+//   resolve   the earliest event is carried out by the 2 (wall) or 4 (pair) lanes that
+//             own the affected chains, exchanging the partner's values by lane shuffles
+//             (carryOutFirstCollision, cpp:219-358, correctOverlap cpp:581-623);
+//   list      the live events sit in registers, one slot per disc (an event's i_ is unique
+//             in the list), replicated across the group; "stable sort descending, pop
+//             the back" (cpp:227,510, Collision.h:24-30) becomes "minimum time, ties to
+//             the most recently inserted".
+//
+// Control flow is uniform inside a group, so shuffles and ballots only ever pair lanes
+// that are active together; different groups of one wave may diverge freely.
+#pragma once
+#include "gsim_common.hpp"
+
+namespace gsim {
+
+template <int GW>
+__device__ __forceinline__ unsigned long long group_ballot(bool pred, int gbase) {
+  unsigned long long m = __ballot(pred);
+  if (GW < 64) m = (m >> gbase) & ((1ull << (GW & 63)) - 1ull);
+  return m;
+}
+
+// Column stride of the LDS grid in doubles: odd, so the "lane <-> column" reads of scan()
+// fall on distinct bank pairs.
+template <int N>
+struct WaveLayout {
+  static constexpr int P = 2 * N, E = P + 1, PK = P;
+  static constexpr int CS = 4 * E + 1;
+  static constexpr int U_OFF = kCols * CS;          // controls: U[e][axis]
+  static constexpr int DOUBLES = U_OFF + 2 * E + 1; // per arena (odd => groups shift banks)
+};
+
+template <int N>
+__device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuck : kRPlayer; }
+
+// One column of insertCollisions (cpp:371-498) for disc `id`: the earliest candidate among
+// UP, DOWN, RIGHT, LEFT and the other discs in entity order; strict '<' keeps the first found.
+template <int N>
+__device__ __forceinline__ void column_candidate(const double *G, int g, int id, double t0, double dt_col,
+                                                 double &best_t, int &best_j, int &best_kind) {
+  using L = WaveLayout<N>;
+  const double *ck = G + g * L::CS;
+  const double *cm = G + (g - 1) * L::CS;
+  const double rad = disc_radius<N>(id);
+  const double kpx = ck[4 * id], kpy = ck[4 * id + 1];
+  const double t_m = t0 + dt_col * (double)(g - 1);          // T row, cpp:201 (g-1 = 0 gives t_)
+  best_t = 1.0e9; best_j = -1; best_kind = -1;               // Collision(), Collision.h:9
+  if (kpy + rad >= kY / 2.0) {                               // cpp:374-394
+    const double mvy = cm[4 * id + 3];
+    if (mvy > 0) {
+      const double tc = t_m + max0(div_ieee(kY / 2.0 - rad - cm[4 * id + 1], mvy));
+      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = UP; }
+    }
+  }
+  if (kpy - rad <= -kY / 2.0) {                              // cpp:397-417
+    const double mvy = cm[4 * id + 3];
+    if (mvy < 0) {
+      const double tc = t_m + max0(div_ieee(-kY / 2.0 + rad - cm[4 * id + 1], mvy));
+      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = DOWN; }
+    }
+  }
+  if (kpx + rad >= kX / 2.0) {                               // cpp:420-440
+    const double mvx = cm[4 * id + 2];
+    if (mvx > 0) {
+      const double tc = t_m + max0(div_ieee(kX / 2.0 - rad - cm[4 * id], mvx));
+      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = RIGHT; }
+    }
+  }
+  if (kpx - rad <= -kX / 2.0) {                              // cpp:443-463
+    const double mvx = cm[4 * id + 2];
+    if (mvx < 0) {
+      const double tc = t_m + max0(div_ieee(-kX / 2.0 + rad - cm[4 * id], mvx));
+      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = LEFT; }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < L::E; ++o) {                           // cpp:466-498
+    if (o == id) continue;
+    const double rad_o = disc_radius<N>(o);
+    const double ddx = kpx - ck[4 * o], ddy = kpy - ck[4 * o + 1];
+    if (sqrt_ieee(ddx * ddx + ddy * ddy) <= rad + rad_o) {   // cpp:471
+      const double dpx = cm[4 * o] - cm[4 * id], dpy = cm[4 * o + 1] - cm[4 * id + 1];         // cpp:484
+      const double dvx = cm[4 * o + 2] - cm[4 * id + 2], dvy = cm[4 * o + 3] - cm[4 * id + 3]; // cpp:485
+      const double sigma = rad + rad_o;
+      const double dpdv = dpx * dvx + dpy * dvy;
+      const double dvdv = dvx * dvx + dvy * dvy;
+      const double dpdp = dpx * dpx + dpy * dpy;
+      const double d = dpdv * dpdv - dvdv * (dpdp - sigma * sigma);                            // cpp:487
+      const double dvdp = dvx * dpx + dvy * dpy;
+      if (dvdp < 0 && d >= 0) {
+        const double tc = t_m + max0(div_ieee(-(dvdp + sqrt_ieee(d)), dvdv));                 // cpp:490
+        if (tc < best_t) { best_t = tc; best_j = o; best_kind = PAIR; }
+      }
+    }
+  }
+}
+
+// insertCollisions' inner loop for one disc (cpp:365-506): first column >= base whose best
+// candidate satisfies t_col - t_ < dt_.  Group-uniform result.
+template <int N, int GW>
+__device__ __forceinline__ bool scan_disc(const double *G, int id, int base, double t0, double dt,
+                                          double dt_col, int lg, int gbase, double &out_t, int &out_j,
+                                          int &out_kind) {
+  for (int g0 = base; g0 <= kGrid; g0 += GW) {
+    const int g = g0 + lg;
+    bool hit = false;
+    double bt = 1.0e9;
+    int bj = -1, bk = -1;
+    if (g <= kGrid) {
+      column_candidate<N>(G, g, id, t0, dt_col, bt, bj, bk);
+      hit = (bt - t0 < dt);                                  // cpp:501
+    }
+    const unsigned long long m = group_ballot<GW>(hit, gbase);
+    if (m != 0ull) {
+      const int src = gbase + __builtin_ctzll(m);
+      out_t = __shfl(bt, src);
+      out_j = __shfl(bj, src);
+      out_kind = __shfl(bk, src);
+      return true;
+    }
+  }
+  return false;
+}
+
+// Live events, one slot per disc (slot index = the event's i_).  meta < 0: empty;
+// else (seq << 8) | (kind << 5) | (j + 1).
+template <int E>
+struct EventSlots {
+  double t[E];
+  int meta[E];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { t[e] = 1.0e9; meta[e] = -1; }
+  }
+  __device__ __forceinline__ void put(int id, double tt, int j, int kind, int seq) {
+    const int m = (seq << 8) | (kind << 5) | (j + 1);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (e == id) { t[e] = tt; meta[e] = m; }
+  }
+  __device__ __forceinline__ bool any() const {
+    int acc = -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc = acc > meta[e] ? acc : meta[e];
+    return acc >= 0;
+  }
+  // Earliest event; among equal times the most recently inserted (largest seq).  Removes it.
+  __device__ __forceinline__ void pop(int &ci, double &ct, int &cj, int &ckind) {
+    ci = -1; ct = 0.0;
+    int cm = -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool valid = meta[e] >= 0;
+      const bool better = valid && (ci < 0 || t[e] < ct || (t[e] == ct && meta[e] > cm));
+      if (better) { ci = e; ct = t[e]; cm = meta[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (e == ci) meta[e] = -1;
+    cj = (cm & 31) - 1;
+    ckind = (cm >> 5) & 7;
+  }
+  // cpp:347-352: drop everything that touches ci or cj (cj = -1 for walls never matches).
+  __device__ __forceinline__ void purge(int ci, int cj) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = (meta[e] & 31) - 1;
+      const bool hit = (e == ci) || (e == cj) || (j != -1 && (j == ci || j == cj));
+      if (meta[e] >= 0 && hit) meta[e] = -1;
+    }
+  }
+};
+
+// Full reference step for arena `a`.  G: this group's LDS region (WaveLayout<N>::DOUBLES).
+// lg: lane index inside the group; gbase: wave lane of the group's lane 0.
+// Returns without touching anything if the game is already decided (cpp:121-123).
+template <int N, int GW>
+__device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a, double *G,
+                                 int lg, int gbase) {
+  using L = WaveLayout<N>;
+  constexpr int E = L::E, PK = L::PK, CS = L::CS;
+  static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
+  const long long B = p.B;
+  double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
+  if (!(TAS < p.win && TBS < p.win)) return;                 // undecided(), cpp:57-60,121
+  const double t0 = p.tcur[a];
+  const double dt = p.dt, dt_col = p.dt_col;
+  double *U = G + L::U_OFF;
+
+  // ---- fill: populateStateGrid, cpp:173-217 ----
+  if (lg < 2 * E) {
+    const int e = lg >> 1, ax = lg & 1;
+    const int row = state_row<N>(e);
+    Chain x;
+    x.p = p.state[(long long)(row + ax) * B + a];
+    x.v = p.state[(long long)(row + 2 + ax) * B + a];
+    double u = 0.0, coef = 0.2, tau = p.tau_puck;            // cpp:188: puck input is (0, 0)
+    if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; }
+    U[2 * e + ax] = u;
+    G[4 * e + ax] = x.p;
+    G[4 * e + 2 + ax] = x.v;
+    for (int i = 1; i <= kGrid; ++i) {
+      x = rk4_axis(x, u, coef, tau, dt_col);
+      G[i * CS + 4 * e + ax] = x.p;
+      G[i * CS + 4 * e + 2 + ax] = x.v;
+    }
+  }
+  wave_sync();
+
+  // ---- event loop, cpp:136-150 ----
+  EventSlots<E> ev;
+  ev.clear();
+  int seq = 0, base = 1, counter = 0;
+  bool scored = false;
+  unsigned n_resolved = 0, n_skipped = 0, n_overflow = 0;
+#pragma unroll
+  for (int id = 0; id < E; ++id) {                           // first pass: checks = all discs, cpp:145
+    double tt; int jj, kk;
+    if (scan_disc<N, GW>(G, id, base, t0, dt, dt_col, lg, gbase, tt, jj, kk)) ev.put(id, tt, jj, kk, seq++);
+  }
+  counter = 1;
+  const bool had_events = ev.any();
+
+  while (ev.any() && counter < kLoopCap) {
+    int ci, cj, ckind;
+    double ct;
+    ev.pop(ci, ct, cj, ckind);                               // cpp:227
+    counter++;
+    if ((ci == PK || cj == PK) && scored) { n_skipped++; continue; }   // cpp:230-231
+    base = (int)__builtin_floor(div_ieee(ct - t0, dt_col)) + 1;        // cpp:237
+    if (base > kGrid) { base = kGrid; n_overflow++; }        // reference: out-of-bounds column
+    if (base < 1) base = 1;
+    n_resolved++;
+    const double dt_t = ct - (t0 + dt_col * (double)(base - 1));       // cpp:254,308
+
+    if (ckind == PAIR) {                                     // cpp:242-299
+      if (lg < 4) {
+        const bool first = lg < 2;                           // lanes 0,1: disc i; lanes 2,3: disc j
+        const int d = first ? ci : cj, ax = lg & 1;
+        const int o = first ? cj : ci;
+        const double r_own = disc_radius<N>(d);
+        const double rsum = disc_radius<N>(ci) + disc_radius<N>(cj);
+        const double m_i = ci == PK ? p.m_puck : p.m_player, m_j = cj == PK ? p.m_puck : p.m_player;
+        const double m_oth = o == PK ? p.m_puck : p.m_player;
+        const double u = U[2 * d + ax];
+        const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
+        Chain x;
+        x.p = G[(base - 1) * CS + 4 * d + ax];
+        x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
+        x = rk4_axis(x, u, coef, tau, dt_t);                 // cpp:255-256
+        {                                                    // cpp:259-265 (pij not normalised)
+          const double po = __shfl_xor(x.p, 2);
+          const double pij = first ? po - x.p : x.p - po;
+          const double sq = pij * pij;
+          const double s = sq + __shfl_xor(sq, 1);
+          const double overlap = rsum - sqrt_ieee(s);
+          if (overlap > 0) {
+            const double c = div_ieee(1.01 * r_own, rsum) * overlap;
+            x.p = first ? x.p - c * pij : x.p + c * pij;
+          }
+        }
+        {                                                    // elastic impulse, cpp:268-274
+          const double po = __shfl_xor(x.p, 2), vo = __shfl_xor(x.v, 2);
+          const double dp = x.p - po, dv = x.v - vo;         // own - other on this axis
+          const double pr = dv * dp, sq = dp * dp;
+          const double dot1 = pr + __shfl_xor(pr, 1);
+          const double dot2 = sq + __shfl_xor(sq, 1);
+          const double s = div_ieee(div_ieee(2 * m_oth, m_i + m_j) * dot1, dot2);
+          if (ci != PK && cj != PK) {                        // damage, cpp:277-282
+            const double dvsq = dv * dv;
+            const double dv_sq = 0.01 * (dvsq + __shfl_xor(dvsq, 1));
+            if (lg == 0) {
+              constexpr int Pn = L::P;
+              p.damage[(long long)(ci * Pn + cj) * B + a] += m_i * dv_sq;
+              p.damage[(long long)(cj * Pn + ci) * B + a] += m_j * dv_sq;
+            }
+          }
+          x.v = x.v - s * dp;
+        }
+        x = rk4_axis(x, u, coef, tau, dt_col - dt_t);        // cpp:287-288
+        for (int g = base; g <= kGrid; ++g) {
+          if (g > base) x = rk4_axis(x, u, coef, tau, dt_col);   // cpp:294-295
+          {                                                  // correctOverlap(i, j), cpp:581-592
+            const double po = __shfl_xor(x.p, 2);
+            const double pij = first ? po - x.p : x.p - po;
+            const double sq = pij * pij;
+            const double s = sq + __shfl_xor(sq, 1);
+            const double overlap = rsum - sqrt_ieee(s);
+            if (overlap > 0) {
+              const double c = div_ieee(1.1 * r_own, rsum) * overlap;
+              x.p = first ? x.p - c * pij : x.p + c * pij;
+            }
+          }
+          G[g * CS + 4 * d + ax] = x.p;
+          G[g * CS + 4 * d + 2 + ax] = x.v;
+        }
+      }
+    } else {                                                 // wall, cpp:300-343
+      bool goal = false;
+      if (lg < 2) {
+        const int d = ci, ax = lg;
+        const double r_own = disc_radius<N>(d);
+        const double u = U[2 * d + ax];
+        const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
+        const bool my_axis = (ckind == UP || ckind == DOWN) ? (ax == 1) : (ax == 0);
+        const bool positive_wall = (ckind == UP || ckind == RIGHT);
+        const double wall = (ckind == UP || ckind == DOWN) ? kY / 2.0 : kX / 2.0;
+        Chain x;
+        x.p = G[(base - 1) * CS + 4 * d + ax];
+        x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
+        x = rk4_axis(x, u, coef, tau, dt_t);                 // cpp:309
+        if (my_axis) {                                       // cpp:314-317
+          if (positive_wall ? (x.v > 0) : (x.v < 0)) x.v *= -1.0;
+        }
+        const double py = __shfl(x.p, gbase + 1);
+        goal = d == PK && (ckind == LEFT || ckind == RIGHT) && py < kGoalH / 2.0 && py > -kGoalH / 2.0;  // cpp:321-322
+        if (goal) {
+          x.p = 0.0; x.v = 0.0;                              // cpp:325
+        } else {
+          x = rk4_axis(x, u, coef, tau, dt_col - dt_t);      // cpp:331
+        }
+        for (int g = base; g <= kGrid; ++g) {
+          if (g > base) x = rk4_axis(x, u, coef, tau, dt_col);   // cpp:338
+          if (my_axis && !(goal && g == base)) {             // correctOverlap(wall), cpp:594-623
+            const double overlap = positive_wall ? (x.p + r_own - wall) : (-x.p + r_own - wall);
+            if (overlap > 0) {
+              const double c = 1.1 * overlap;
+              x.p = positive_wall ? x.p - c : x.p + c;
+            }
+          }
+          G[g * CS + 4 * d + ax] = x.p;
+          G[g * CS + 4 * d + 2 + ax] = x.v;
+        }
+      }
+      goal = __shfl(goal ? 1 : 0, gbase) != 0;
+      if (goal) {                                            // cpp:324-326
+        if (!scored) { if (ckind == RIGHT) TAS += 1.0; else TBS += 1.0; }
+        scored = true;
+      }
+    }
+    wave_sync();
+
+    ev.purge(ci, cj);                                        // cpp:347-352
+    {                                                        // re-scan i_ then j_, cpp:355-357 -> 147
+      double tt; int jj, kk;
+      if (scan_disc<N, GW>(G, ci, base, t0, dt, dt_col, lg, gbase, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
+      if (cj >= 0 && scan_disc<N, GW>(G, cj, base, t0, dt, dt_col, lg, gbase, tt, jj, kk))
+        ev.put(cj, tt, jj, kk, seq++);
+    }
+  }
+
+  // ---- commit: column 50 -> state, t_ += dt_ (cpp:153-158) ----
+  if (lg < 2 * E) {
+    const int e = lg >> 1, ax = lg & 1;
+    const int row = state_row<N>(e);
+    p.state[(long long)(row + ax) * B + a] = G[kGrid * CS + 4 * e + ax];
+    p.state[(long long)(row + 2 + ax) * B + a] = G[kGrid * CS + 4 * e + 2 + ax];
+  }
+  if (lg == 0) {
+    p.tcur[a] = t0 + dt;
+    if (scored) { p.state[0 * B + a] = TAS; p.state[1 * B + a] = TBS; }
+    if (had_events) {
+      atomicAdd(&p.counters[CNT_EVENT_STEPS], 1ull);
+      if (n_resolved) atomicAdd(&p.counters[CNT_RESOLVED], (unsigned long long)n_resolved);
+      if (ev.any()) atomicAdd(&p.counters[CNT_CAP_HITS], 1ull);
+      if (n_overflow) atomicAdd(&p.counters[CNT_BASE_OVERFLOW], (unsigned long long)n_overflow);
+      if (n_skipped) atomicAdd(&p.counters[CNT_SKIPPED], (unsigned long long)n_skipped);
+    }
+  }
+  wave_sync();   // the next step's fill must not overtake this step's column-50 reads
+}
+
+}  // namespace gsim

@@ -1,0 +1,427 @@
+// rgs_hip.hip -- kernels and C ABI of the MI355X batched stepper (see include/rgs_hip.h).
+// gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rgs_hip.h"
+#include "gsim_common.hpp"
+#include "gsim_wave.hpp"
+
+using namespace gsim;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(RGS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+constexpr int kWavesPerBlock = 4;
+
+// ---------------------------------------------------------------------------------------
+// Kernels
+// ---------------------------------------------------------------------------------------
+
+// One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
+// the SoA arrays (L2-resident) between steps.
+template <int N, int GW>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
+  extern __shared__ double lds[];
+  using L = WaveLayout<N>;
+  constexpr int GPW = 64 / GW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / GW, lg = lane % GW;
+  const long long a = ((long long)blockIdx.x * kWavesPerBlock + wave) * GPW + grp;
+  if (a >= p.B) return;
+  double *G = lds + (wave * GPW + grp) * L::DOUBLES;
+  for (int k = 0; k < p.n_steps; ++k)
+    arena_step_group<N, GW>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg);
+}
+
+// GameSim::reset on the device (src/GameSim.cpp:27-39); players spawn in rows (n = 2: +-Y/4).
+template <int N>
+__global__ void k_reset(double *state, double *tcur, double *damage, const double *x0, int x0_batched,
+                        long long B) {
+  constexpr int P = 2 * N, E = P + 1;
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= B) return;
+  state[0 * B + a] = 0.0;
+  state[1 * B + a] = 0.0;
+  for (int c = 0; c < 4; ++c) state[(long long)(2 + c) * B + a] = x0_batched ? x0[(long long)c * B + a] : x0[c];
+  for (int e = 0; e < P; ++e) {
+    const int k = e < N ? e : e - N;
+    const double y = kY / 2.0 - (2 * k + 1) * kY / (2.0 * N);
+    const double x = e < N ? -kX / 4.0 : kX / 4.0;
+    const int row = 6 + 4 * e;
+    state[(long long)(row + 0) * B + a] = x;
+    state[(long long)(row + 1) * B + a] = y;
+    state[(long long)(row + 2) * B + a] = 0.0;
+    state[(long long)(row + 3) * B + a] = 0.0;
+  }
+  for (int q = 0; q < P * P; ++q) damage[(long long)q * B + a] = 0.0;
+  tcur[a] = 0.0;
+  (void)E;
+}
+
+__global__ void k_undecided(const double *state, long long B, double win, uint8_t *out) {
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= B) return;
+  out[a] = (state[a] < win && state[B + a] < win) ? 1 : 0;
+}
+
+__global__ void k_selftest(const double *a, const double *b, long long n, double *q, double *s) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  q[i] = div_ieee(a[i], b[i]);
+  s[i] = sqrt_ieee(a[i]);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------
+
+struct rgs_sim {
+  long long B = 0;
+  int n = 2, P = 4, E = 5, S = 22;
+  int device = 0;
+  int variant = RGS_VARIANT_AUTO;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double *state = nullptr, *tcur = nullptr, *damage = nullptr, *ctl = nullptr;
+  unsigned long long *counters = nullptr;
+  uint8_t *flags = nullptr;
+  // reset() parameters, src/GameSim.cpp:27-46
+  double dt = 0.05, dt_col = 0.05 / kGrid, tau_puck = 0.1, tau_player = 0.5, m_player = 1.0, m_puck = 0.5;
+  int win = 3, seed = 0;
+};
+
+namespace {
+
+template <int N>
+int launch_wave(rgs_sim *s, const StepArgs &args) {
+  constexpr int GW = 64;
+  constexpr int GPW = 64 / GW;
+  const long long per_block = (long long)kWavesPerBlock * GPW;
+  const long long blocks = (s->B + per_block - 1) / per_block;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * per_block;
+  hipLaunchKernelGGL((k_step_wave<N, GW>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave launch: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
+int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps) {
+  StepArgs a;
+  a.dt = s->dt; a.dt_col = s->dt_col;
+  a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
+  a.m_player = s->m_player; a.m_puck = s->m_puck;
+  a.win = (double)s->win;
+  a.B = s->B;
+  a.state = s->state; a.tcur = s->tcur; a.damage = s->damage;
+  a.ctl = ctl_dev; a.ctl_stride = stride; a.n_steps = n_steps;
+  a.counters = s->counters;
+  a.queue = nullptr; a.queue_count = nullptr;
+  switch (s->n) {
+    case 1: return launch_wave<1>(s, a);
+    case 2: return launch_wave<2>(s, a);
+    case 3: return launch_wave<3>(s, a);
+    case 4: return launch_wave<4>(s, a);
+    case 5: return launch_wave<5>(s, a);
+    case 6: return launch_wave<6>(s, a);
+    case 7: return launch_wave<7>(s, a);
+  }
+  return fail(RGS_ERR_ARG, "n_per_team out of range");
+}
+
+template <int N>
+void launch_reset(rgs_sim *s, const double *x0_dev, int batched) {
+  const int tb = 256;
+  hipLaunchKernelGGL((k_reset<N>), dim3((unsigned)((s->B + tb - 1) / tb)), dim3(tb), 0, s->stream, s->state,
+                     s->tcur, s->damage, x0_dev, batched, s->B);
+}
+
+int do_reset(rgs_sim *s, const double *x0_host, int batched) {
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t n = batched ? (size_t)4 * s->B : 4;
+  double *x0_dev = nullptr;
+  HIP_TRY(hipMalloc(&x0_dev, n * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(x0_dev, x0_host, n * sizeof(double), hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) {
+    switch (s->n) {
+      case 1: launch_reset<1>(s, x0_dev, batched); break;
+      case 2: launch_reset<2>(s, x0_dev, batched); break;
+      case 3: launch_reset<3>(s, x0_dev, batched); break;
+      case 4: launch_reset<4>(s, x0_dev, batched); break;
+      case 5: launch_reset<5>(s, x0_dev, batched); break;
+      case 6: launch_reset<6>(s, x0_dev, batched); break;
+      case 7: launch_reset<7>(s, x0_dev, batched); break;
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemsetAsync(s->counters, 0, CNT_N * sizeof(unsigned long long), s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  hipFree(x0_dev);
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("reset: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rgs_last_error(void) { return g_err.c_str(); }
+
+int rgs_state_size(int n_per_team) { return 2 + 4 * (2 * n_per_team + 1); }
+
+int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
+  if (!out || n_arenas < 1 || n_per_team < 1 || n_per_team > 7) return fail(RGS_ERR_ARG, "rgs_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(RGS_ERR_NO_DEVICE, "no HIP device visible");
+  if (device_id < 0 || device_id >= ndev) return fail(RGS_ERR_ARG, "rgs_create: device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RGS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  rgs_sim *s = new rgs_sim();
+  s->B = n_arenas;
+  s->n = n_per_team;
+  s->P = 2 * n_per_team;
+  s->E = s->P + 1;
+  s->S = 2 + 4 * s->E;
+  s->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+  if (e == hipSuccess) e = hipMalloc(&s->state, sizeof(double) * s->S * s->B);
+  if (e == hipSuccess) e = hipMalloc(&s->tcur, sizeof(double) * s->B);
+  if (e == hipSuccess) e = hipMalloc(&s->damage, sizeof(double) * s->P * s->P * s->B);
+  if (e == hipSuccess) e = hipMalloc(&s->ctl, sizeof(double) * s->P * 2 * s->B);
+  if (e == hipSuccess) e = hipMalloc(&s->counters, sizeof(unsigned long long) * CNT_N);
+  if (e == hipSuccess) e = hipMalloc(&s->flags, (size_t)s->B);
+  if (e != hipSuccess) {
+    std::string m = std::string("rgs_create: ") + hipGetErrorString(e);
+    rgs_destroy(s);
+    return fail(RGS_ERR_HIP, m);
+  }
+  const double zero[4] = {0, 0, 0, 0};
+  int rc = do_reset(s, zero, 0);                 // C++ defaults, src/GameSim.cpp:21-25
+  if (rc != RGS_OK) { rgs_destroy(s); return rc; }
+  *out = s;
+  return RGS_OK;
+}
+
+int rgs_destroy(rgs_sim *s) {
+  if (!s) return RGS_OK;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  hipFree(s->state); hipFree(s->tcur); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+  return RGS_OK;
+}
+
+int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_host, int x0_batched, double noise,
+              int seed, double tau_puck, double tau_player, double player_mass, double puck_mass) {
+  if (!s || !x0_ball_host) return fail(RGS_ERR_ARG, "rgs_reset: null argument");
+  if (noise != 0.0)
+    return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 is not implemented on the device (SURVEY 8f-3)");
+  s->dt = dt;
+  s->dt_col = dt / kGrid;                        // cpp:28
+  s->win = winning_score;
+  s->seed = seed;
+  s->tau_puck = tau_puck; s->tau_player = tau_player;
+  s->m_player = player_mass; s->m_puck = puck_mass;
+  return do_reset(s, x0_ball_host, x0_batched);
+}
+
+int rgs_step(rgs_sim *s, const double *controls_host) {
+  if (!s || !controls_host) return fail(RGS_ERR_ARG, "rgs_step: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(s->ctl, controls_host, sizeof(double) * s->P * 2 * s->B, hipMemcpyHostToDevice, s->stream));
+  int rc = launch_steps(s, s->ctl, 0, 1);
+  if (rc != RGS_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));      // controls_host may be reused by the caller
+  return RGS_OK;
+}
+
+int rgs_step_device(rgs_sim *s, const double *controls_dev, int64_t step_stride, int n_steps) {
+  if (!s || !controls_dev || n_steps < 0 || step_stride < 0) return fail(RGS_ERR_ARG, "rgs_step_device: bad argument");
+  if (n_steps == 0) return RGS_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  return launch_steps(s, controls_dev, step_stride, n_steps);
+}
+
+int rgs_sync(rgs_sim *s) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_sync: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_get_state(rgs_sim *s, double *out) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_get_state: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(out, s->state, sizeof(double) * s->S * s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_undecided(rgs_sim *s, uint8_t *out) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_undecided: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const int tb = 256;
+  hipLaunchKernelGGL(k_undecided, dim3((unsigned)((s->B + tb - 1) / tb)), dim3(tb), 0, s->stream, s->state, s->B,
+                     (double)s->win, s->flags);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, s->flags, (size_t)s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_get_damage(rgs_sim *s, double *out) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_get_damage: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(out, s->damage, sizeof(double) * s->P * s->P * s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_get_time(rgs_sim *s, double *out) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_get_time: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(out, s->tcur, sizeof(double) * s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_set_state(rgs_sim *s, const double *state_host, const double *time_host) {
+  if (!s || !state_host || !time_host) return fail(RGS_ERR_ARG, "rgs_set_state: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(s->state, state_host, sizeof(double) * s->S * s->B, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->tcur, time_host, sizeof(double) * s->B, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemsetAsync(s->damage, 0, sizeof(double) * s->P * s->P * s->B, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_state_device_ptr(rgs_sim *s, double **out) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_state_device_ptr: null argument");
+  *out = s->state;
+  return RGS_OK;
+}
+
+int rgs_copy_state_to_device(rgs_sim *s, double *dst) {
+  if (!s || !dst) return fail(RGS_ERR_ARG, "rgs_copy_state_to_device: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(dst, s->state, sizeof(double) * s->S * s->B, hipMemcpyDeviceToDevice, s->stream));
+  return RGS_OK;
+}
+
+int rgs_stream(rgs_sim *s, void **out) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_stream: null argument");
+  *out = (void *)s->stream;
+  return RGS_OK;
+}
+
+int rgs_device_alloc(rgs_sim *s, int64_t n, double **out) {
+  if (!s || !out || n < 1) return fail(RGS_ERR_ARG, "rgs_device_alloc: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMalloc(out, sizeof(double) * (size_t)n));
+  return RGS_OK;
+}
+
+int rgs_device_free(rgs_sim *s, double *dev) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_device_free: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipFree(dev));
+  return RGS_OK;
+}
+
+int rgs_device_upload(rgs_sim *s, double *dst, const double *src, int64_t n) {
+  if (!s || !dst || !src || n < 0) return fail(RGS_ERR_ARG, "rgs_device_upload: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_device_download(rgs_sim *s, double *dst, const double *src, int64_t n) {
+  if (!s || !dst || !src || n < 0) return fail(RGS_ERR_ARG, "rgs_device_download: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_timer_start(rgs_sim *s) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_timer_start: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventRecord(s->ev0, s->stream));
+  return RGS_OK;
+}
+
+int rgs_timer_stop(rgs_sim *s, float *ms_out) {
+  if (!s || !ms_out) return fail(RGS_ERR_ARG, "rgs_timer_stop: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventRecord(s->ev1, s->stream));
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  HIP_TRY(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+  return RGS_OK;
+}
+
+int rgs_get_counters(rgs_sim *s, int64_t *out8) {
+  if (!s || !out8) return fail(RGS_ERR_ARG, "rgs_get_counters: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(out8, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_set_variant(rgs_sim *s, int variant) {
+  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_HYBRID) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
+  s->variant = variant;
+  return RGS_OK;
+}
+
+int rgs_selftest_math(int device_id, const double *a_host, const double *b_host, int64_t n, double *quot_host,
+                      double *sqrt_host) {
+  if (!a_host || !b_host || !quot_host || !sqrt_host || n < 1) return fail(RGS_ERR_ARG, "rgs_selftest_math: bad argument");
+  HIP_TRY(hipSetDevice(device_id));
+  double *a = nullptr, *b = nullptr, *q = nullptr, *r = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  HIP_TRY(hipMalloc(&a, bytes));
+  HIP_TRY(hipMalloc(&b, bytes));
+  HIP_TRY(hipMalloc(&q, bytes));
+  HIP_TRY(hipMalloc(&r, bytes));
+  HIP_TRY(hipMemcpy(a, a_host, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b, b_host, bytes, hipMemcpyHostToDevice));
+  const int tb = 256;
+  hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, 0, a, b, (long long)n, q, r);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(quot_host, q, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sqrt_host, r, bytes, hipMemcpyDeviceToHost));
+  hipFree(a); hipFree(b); hipFree(q); hipFree(r);
+  return RGS_OK;
+}
+
+}  // extern "C"

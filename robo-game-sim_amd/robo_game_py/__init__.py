@@ -1,0 +1,343 @@
+"""robo_game_py -- MI355X-native drop-in for the reference's pybind11 module of the same name.
+
+The reference builds `robo_game_py` from src/RoboGamePy.cpp:11-25 and its callers do
+`from robo_game_py import GameSim` (py/run_sim.py:3, py/MonteCarlo.py:1).  Put this
+directory's parent (`robo-game-sim_amd/`) on PYTHONPATH and the same import resolves here:
+
+    GameSim          one arena; reset / undecided / run / repr exactly as the binding
+                     (include/GameSim.h:21-27), every step executed by the HIP stepper.
+    BatchedGameSim   many independent arenas resident on one GPU (SoA, arena index fastest).
+
+All physics runs in librgs_hip.so (hand-written HIP for gfx950) through the C ABI of
+include/rgs_hip.h.  There is no CPU fallback.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _lib
+from ._lib import RgsError, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_WAVE  # noqa: F401
+
+__all__ = ["GameSim", "BatchedGameSim", "SimStateView", "RgsError", "reset_arguments", "state_size",
+           "log_record"]
+
+# C++ defaults of GameSim::reset, src/GameSim.cpp:21-25 (the binding itself declares none, so the
+# reference needs all 11 positionals; py/run_sim.py:43 passes 6 -- both arities are accepted here).
+_RESET_NAMES = ("dt", "winning_score", "x0_ball", "noise", "log", "logname", "seed", "tau_puck",
+                "tau_player", "player_mass", "puck_mass")
+_RESET_DEFAULTS = (0.05, 3, None, 0.0, False, "~/gamelog.log", 0, 0.1, 0.5, 1.0, 0.5)
+
+
+def state_size(n_per_team=2):
+    """SimState::SIZE (include/SimState.h:22): 2 scores + 4 doubles per disc."""
+    return 2 + 4 * (2 * n_per_team + 1)
+
+
+def reset_arguments(*args, **kwargs):
+    """Normalise reset(...) arguments to the full 11-tuple of include/GameSim.h:21-24."""
+    if len(args) > len(_RESET_NAMES):
+        raise TypeError("reset() takes at most %d arguments (%d given)" % (len(_RESET_NAMES), len(args)))
+    vals = dict(zip(_RESET_NAMES, _RESET_DEFAULTS))
+    vals.update(zip(_RESET_NAMES, args))
+    for k, v in kwargs.items():
+        if k not in vals:
+            raise TypeError("reset() got an unexpected keyword argument %r" % k)
+        if k in _RESET_NAMES[:len(args)]:
+            raise TypeError("reset() got multiple values for argument %r" % k)
+        vals[k] = v
+    out = dict(vals)
+    out["dt"] = float(out["dt"])
+    out["winning_score"] = int(out["winning_score"])
+    out["noise"] = float(out["noise"])
+    out["log"] = bool(out["log"])
+    out["logname"] = str(out["logname"])
+    out["seed"] = int(out["seed"])
+    for k in ("tau_puck", "tau_player", "player_mass", "puck_mass"):
+        out[k] = float(out[k])
+    return out
+
+
+def log_record(t, state, damage):
+    """One record of the reference's binary log (src/GameSim.cpp:161-170, include/utils.h:64-76).
+
+    3 + 2 + 2P + P*P native-endian doubles (29 at 2v2): t, TAS, TBS, puck xy, each player's xy,
+    then the reference's `damage.row(k)` blocks.  logVectors writes rows*cols CONTIGUOUS doubles
+    starting at &damage(k, 0) of a column-major matrix, so block k holds flat elements k..k+P-1
+    of the column-major array, not row k; that byte layout is reproduced as is.
+    """
+    state = np.asarray(state, dtype=np.float64)
+    damage = np.asarray(damage, dtype=np.float64)
+    P = damage.shape[0]
+    rec = [float(t), state[0], state[1], state[2], state[3]]
+    for e in range(P):
+        rec += [state[6 + 4 * e], state[7 + 4 * e]]
+    flat = damage.flatten(order="F")
+    for k in range(P):
+        rec += list(flat[k:k + P])
+    return struct.pack("=%dd" % len(rec), *rec)
+
+
+class SimStateView:
+    """Index helper over a state vector, N-generic counterpart of py/src/SimState.py:6-12."""
+
+    def __init__(self, state, n_per_team=2):
+        self.state = np.array(state, dtype=np.float64, copy=True)
+        self.n = int(n_per_team)
+        self.TAS, self.TBS, self.PK = 0, 1, 2
+
+    def offset(self, team, player_id):
+        k = {"A": 0, "B": self.n}[team] + (player_id - 1)
+        return 6 + 4 * k
+
+    def get_player_state(self, team, player_id):
+        o = self.offset(team, player_id)
+        return self.state[o:o + 4].copy()
+
+    def get_puck_state(self):
+        return self.state[2:6].copy()
+
+
+class _DeviceBuffer:
+    """Doubles resident in HBM, owned by a BatchedGameSim."""
+
+    def __init__(self, sim, n):
+        self._sim = sim
+        self.n = int(n)
+        p = C.c_void_p()
+        _lib.check(_lib.lib().rgs_device_alloc(sim._h, self.n, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host, offset=0):
+        a = np.ascontiguousarray(host, dtype=np.float64)
+        assert offset + a.size <= self.n
+        _lib.check(_lib.lib().rgs_device_upload(self._sim._h, C.c_void_p(self.ptr + 8 * offset), _lib.dptr(a), a.size))
+
+    def download(self, n=None, offset=0):
+        n = self.n - offset if n is None else int(n)
+        out = np.empty(n)
+        _lib.check(_lib.lib().rgs_device_download(self._sim._h, _lib.dptr(out), C.c_void_p(self.ptr + 8 * offset), n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.check(_lib.lib().rgs_device_free(self._sim._h, C.c_void_p(self.ptr)))
+            self.ptr = None
+
+
+class BatchedGameSim:
+    """`n_arenas` independent games on one MI355X.
+
+    Arrays follow the device layout, arena index fastest:
+    state (S, B), controls (P, 2, B), x0_ball (4,) or (4, B), damage (P, P, B), time (B,).
+    """
+
+    def __init__(self, n_arenas, n_per_team=2, device=0):
+        self._L = _lib.lib()
+        self._h = None
+        h = C.c_void_p()
+        _lib.check(self._L.rgs_create(int(n_arenas), int(n_per_team), int(device), C.byref(h)))
+        self._h = h
+        self.n_arenas = int(n_arenas)
+        self.n_per_team = int(n_per_team)
+        self.players = 2 * self.n_per_team
+        self.state_size = state_size(self.n_per_team)
+        self.device = int(device)
+        self.params = reset_arguments()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rgs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference surface, batched -------------------------------------------------------
+    def reset(self, *args, **kwargs):
+        """GameSim::reset for every arena; x0_ball may be (4,) or (4, B).  Returns state (S, B)."""
+        a = reset_arguments(*args, **kwargs)
+        x0 = np.zeros(4) if a["x0_ball"] is None else np.ascontiguousarray(a["x0_ball"], dtype=np.float64)
+        if x0.shape == (4,):
+            batched = 0
+        elif x0.shape == (4, self.n_arenas):
+            batched = 1
+        else:
+            raise TypeError("x0_ball must have shape (4,) or (4, n_arenas), got %r" % (x0.shape,))
+        _lib.check(self._L.rgs_reset(self._h, a["dt"], a["winning_score"], _lib.dptr(x0), batched, a["noise"],
+                                     a["seed"], a["tau_puck"], a["tau_player"], a["player_mass"], a["puck_mass"]))
+        self.params = a
+        return self.state()
+
+    def undecided(self):
+        out = np.empty(self.n_arenas, dtype=np.uint8)
+        _lib.check(self._L.rgs_undecided(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out.astype(bool)
+
+    def run(self, controls):
+        """GameSim::run for every arena with host controls (P, 2, B); returns state (S, B)."""
+        self.step(controls)
+        return self.state()
+
+    # -- batched extras -------------------------------------------------------------------
+    def step(self, controls):
+        c = np.ascontiguousarray(controls, dtype=np.float64)
+        if c.shape != (self.players, 2, self.n_arenas):
+            raise TypeError("controls must have shape (%d, 2, %d), got %r" % (self.players, self.n_arenas, c.shape))
+        _lib.check(self._L.rgs_step(self._h, _lib.dptr(c)))
+
+    def step_device(self, ctl_ptr, step_stride, n_steps):
+        """Asynchronous: n_steps steps reading controls from device memory (ints are raw pointers)."""
+        ptr = ctl_ptr.ptr if isinstance(ctl_ptr, _DeviceBuffer) else int(ctl_ptr)
+        _lib.check(self._L.rgs_step_device(self._h, C.c_void_p(ptr), int(step_stride), int(n_steps)))
+
+    def run_table(self, table, chunk_steps=256):
+        """Step through a host control table (K, P, 2, B), uploaded in chunks; returns state (S, B)."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        K = t.shape[0]
+        if t.shape[1:] != (self.players, 2, self.n_arenas):
+            raise TypeError("table must have shape (K, %d, 2, %d)" % (self.players, self.n_arenas))
+        stride = self.players * 2 * self.n_arenas
+        buf = self.alloc(min(K, chunk_steps) * stride)
+        try:
+            for k0 in range(0, K, chunk_steps):
+                k1 = min(K, k0 + chunk_steps)
+                buf.upload(t[k0:k1])
+                self.step_device(buf, stride, k1 - k0)
+                self.sync()
+        finally:
+            buf.free()
+        return self.state()
+
+    def sync(self):
+        _lib.check(self._L.rgs_sync(self._h))
+
+    def state(self):
+        out = np.empty((self.state_size, self.n_arenas))
+        _lib.check(self._L.rgs_get_state(self._h, _lib.dptr(out)))
+        return out
+
+    def damage(self):
+        out = np.empty((self.players, self.players, self.n_arenas))
+        _lib.check(self._L.rgs_get_damage(self._h, _lib.dptr(out)))
+        return out
+
+    def time(self):
+        out = np.empty(self.n_arenas)
+        _lib.check(self._L.rgs_get_time(self._h, _lib.dptr(out)))
+        return out
+
+    def set_state(self, state, time=None):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        if s.shape != (self.state_size, self.n_arenas):
+            raise TypeError("state must have shape (%d, %d)" % (self.state_size, self.n_arenas))
+        t = np.zeros(self.n_arenas) if time is None else np.ascontiguousarray(
+            np.broadcast_to(np.asarray(time, dtype=np.float64), (self.n_arenas,)))
+        _lib.check(self._L.rgs_set_state(self._h, _lib.dptr(s), _lib.dptr(t)))
+
+    def counters(self):
+        out = (C.c_int64 * 8)()
+        _lib.check(self._L.rgs_get_counters(self._h, out))
+        names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps"]
+        return dict(zip(names, list(out)[:5]))
+
+    def set_variant(self, variant):
+        _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
+
+    def alloc(self, n_doubles):
+        return _DeviceBuffer(self, n_doubles)
+
+    def state_device_ptr(self):
+        p = C.c_void_p()
+        _lib.check(self._L.rgs_state_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def copy_state_to(self, dst_dev_ptr):
+        _lib.check(self._L.rgs_copy_state_to_device(self._h, C.c_void_p(int(dst_dev_ptr))))
+
+    def timer_start(self):
+        _lib.check(self._L.rgs_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.check(self._L.rgs_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+class GameSim:
+    """Drop-in for the reference's `robo_game_py.GameSim` (src/RoboGamePy.cpp:15-24).
+
+    reset(dt, winning_score, x0_ball, noise, log, logname, seed, tau_puck, tau_player,
+    player_mass, puck_mass) -> ndarray(S,); undecided() -> bool; run(vel...) -> ndarray(S,).
+    6 to 11 positional arguments are accepted with the C++ defaults of src/GameSim.cpp:21-25.
+    `n_per_team` (default 2, the reference's only size) is an extension; run() then takes 2n
+    velocity arguments in disc order A1..An, B1..Bn, or one array of shape (2n, 2).
+    """
+
+    def __init__(self, n_per_team=2, device=0):
+        self._b = BatchedGameSim(1, n_per_team, device)
+        self.n_per_team = int(n_per_team)
+        self._log = None
+        self._ctl = np.zeros((self._b.players, 2, 1))
+
+    def __repr__(self):
+        return "GameSim Object"                      # src/RoboGamePy.cpp:20-23
+
+    def _close_log(self):
+        if self._log is not None:
+            self._log.close()
+            self._log = None
+
+    def __del__(self):
+        try:
+            self._close_log()
+        except Exception:
+            pass
+
+    def reset(self, *args, **kwargs):
+        a = reset_arguments(*args, **kwargs)
+        x0 = np.zeros(4) if a["x0_ball"] is None else np.asarray(a["x0_ball"], dtype=np.float64).reshape(-1)
+        if x0.shape != (4,):
+            raise TypeError("x0_ball must hold 4 doubles")
+        a["x0_ball"] = x0
+        state = self._b.reset(**a)
+        self._close_log()                            # src/GameSim.cpp:48-53
+        if a["log"]:
+            try:
+                self._log = open(a["logname"], "wb")
+            except OSError:
+                self._log = None                     # std::ofstream fails silently (include/utils.h:55-60)
+        return state[:, 0].copy()
+
+    def undecided(self):
+        return bool(self._b.undecided()[0])
+
+    def run(self, *vels):
+        P = self._b.players
+        if len(vels) == 1 and np.asarray(vels[0]).size == 2 * P:
+            u = np.asarray(vels[0], dtype=np.float64).reshape(P, 2)
+        elif len(vels) == P:
+            u = np.stack([np.asarray(v, dtype=np.float64).reshape(2) for v in vels])
+        else:
+            raise TypeError("run() takes %d velocity arguments of shape (2,) (%d given)" % (P, len(vels)))
+        was_live = self._log is not None and self.undecided()
+        self._ctl[:, :, 0] = u
+        self._b.step(self._ctl)
+        state = self._b.state()[:, 0].copy()
+        if was_live:                                 # a decided game logs nothing, src/GameSim.cpp:121-123
+            self._log.write(log_record(self._b.time()[0], state, self._b.damage()[:, :, 0]))
+            self._log.flush()
+        return state
+
+    # extras (not part of the reference binding)
+    def damage(self):
+        return self._b.damage()[:, :, 0].copy()
+
+    def time(self):
+        return float(self._b.time()[0])
+
+    def set_state(self, state, t=0.0):
+        self._b.set_state(np.asarray(state, dtype=np.float64).reshape(-1, 1), t)

@@ -1,0 +1,97 @@
+"""ctypes binding of librgs_hip.so (C ABI declared in include/rgs_hip.h).
+
+There is no CPU fallback: if the HIP library cannot be loaded, importing the
+product raises, and every failed call raises RgsError with the library's text.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC, "librgs_hip.so")
+
+RGS_OK = 0
+RGS_ERR_ARG = -1
+RGS_ERR_HIP = -2
+RGS_ERR_UNSUPPORTED = -3
+RGS_ERR_NO_DEVICE = -4
+
+VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/rgs_hip.h one-to-one
+SIGNATURES = {
+    "rgs_last_error": (C.c_char_p, []),
+    "rgs_state_size": (C.c_int, [C.c_int]),
+    "rgs_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rgs_destroy": (C.c_int, [_vp]),
+    "rgs_reset": (C.c_int, [_vp, C.c_double, C.c_int, _dp, C.c_int, C.c_double, C.c_int, C.c_double,
+                            C.c_double, C.c_double, C.c_double]),
+    "rgs_step": (C.c_int, [_vp, _dp]),
+    "rgs_step_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "rgs_sync": (C.c_int, [_vp]),
+    "rgs_get_state": (C.c_int, [_vp, _dp]),
+    "rgs_undecided": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
+    "rgs_get_damage": (C.c_int, [_vp, _dp]),
+    "rgs_get_time": (C.c_int, [_vp, _dp]),
+    "rgs_set_state": (C.c_int, [_vp, _dp, _dp]),
+    "rgs_state_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "rgs_copy_state_to_device": (C.c_int, [_vp, _vp]),
+    "rgs_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "rgs_device_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "rgs_device_free": (C.c_int, [_vp, _vp]),
+    "rgs_device_upload": (C.c_int, [_vp, _vp, _dp, C.c_int64]),
+    "rgs_device_download": (C.c_int, [_vp, _dp, _vp, C.c_int64]),
+    "rgs_timer_start": (C.c_int, [_vp]),
+    "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
+    "rgs_selftest_math": (C.c_int, [C.c_int, _dp, _dp, C.c_int64, _dp, _dp]),
+}
+
+
+class RgsError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("librgs_hip: %s (status %d)" % (text, code))
+        self.code = code
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile librgs_hip.so in-tree with hipcc for gfx950 (works without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args + ["librgs_hip.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """Load the HIP library, failing loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "robo_game_py: %s is missing. Build it with `make -C %s` (needs hipcc); "
+                "there is no CPU fallback." % (LIB_PATH, CSRC))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != RGS_OK:
+        raise RgsError(code, (lib().rgs_last_error() or b"").decode(errors="replace"))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)

@@ -1,0 +1,235 @@
+"""HIP stepper vs. the CPU oracle on identical inputs (all through the C ABI via robo_game_py).
+
+Bar (BASELINE.json north_star): positions / velocities within 1e-5 of the reference step for
+step, scores bit-exact.  The dynamics are chaotic once discs collide, so in practice the only
+way to stay inside 1e-5 is to be bit-identical; the tests therefore assert exact equality
+(numeric ==, which lets -0.0 equal +0.0) and report max |delta| for the written tolerance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def assert_same(gpu, ref, what):
+    gpu = np.asarray(gpu)
+    ref = np.asarray(ref)
+    if gpu.dtype == bool:
+        gpu, ref = gpu.astype(np.int8), ref.astype(np.int8)
+    assert gpu.shape == ref.shape
+    err = float(np.max(np.abs(gpu - ref))) if gpu.size else 0.0
+    assert err <= TOL, "%s: max |delta| = %g > %g" % (what, err, TOL)
+    bad = np.argwhere(gpu != ref)
+    assert bad.size == 0, "%s: %d values differ (max |delta| %g), first at %s" % (what, len(bad), err, bad[:4].tolist())
+
+
+def run_both(rgp, oracle, n, x0, table, dt, win=1000000, rec_every=0, variant=None, **phys):
+    K, P, _, B = table.shape
+    sim = rgp.BatchedGameSim(B, n)
+    if variant is not None:
+        sim.set_variant(variant)
+    sim.reset(dt, win, x0, 0.0, False, "", 0, phys.get("tau_puck", 0.1), phys.get("tau_player", 0.5),
+              phys.get("player_mass", 1.0), phys.get("puck_mass", 0.5))
+    traj = []
+    if rec_every:
+        stride = P * 2 * B
+        buf = sim.alloc(K * stride)
+        buf.upload(table)
+        for k0 in range(0, K, rec_every):
+            sim.step_device(buf.ptr + 8 * k0 * stride, stride, min(rec_every, K - k0))
+            traj.append(sim.state())
+        buf.free()
+        state = traj[-1] if K % rec_every == 0 else sim.state()
+    else:
+        state = sim.run_table(table)
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=win, rec_every=rec_every, n_threads=8,
+                           want_damage=True, **phys)
+    out = dict(state=state, traj=np.stack(traj) if traj else None, damage=sim.damage().reshape(P * P, B),
+               time=sim.time(), counters=sim.counters(), undecided=sim.undecided())
+    sim.close()
+    return out, ref
+
+
+def check(out, ref, what):
+    assert_same(out["state"][:2], ref["state"][:2], what + " scores")
+    assert_same(out["state"], ref["state"], what + " final state")
+    assert_same(out["damage"], ref["damage"], what + " damage")
+    if out["traj"] is not None and ref["traj"] is not None:
+        n = min(len(out["traj"]), len(ref["traj"]))
+        assert_same(out["traj"][:n], ref["traj"][:n], what + " trajectory")
+    st = ref["stats"]
+    c = out["counters"]
+    assert c["resolved"] == st["resolved"], (c, st)
+    assert c["cap_hits"] == st["cap_hits"], (c, st)
+    assert c["skipped_after_goal"] == st["skipped_after_goal"], (c, st)
+    assert c["base_overflow"] == st["base_overflow"], (c, st)
+
+
+def test_device_division_and_sqrt_are_ieee(rgp):
+    """The parity argument rests on correctly rounded fp64 '/' and sqrt on the device."""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    n = 1 << 21
+    a = np.concatenate([rng.uniform(0, 10, n // 2), np.exp(rng.uniform(-300, 300, n // 2))])
+    b = np.concatenate([rng.uniform(-10, 10, n // 2), np.exp(rng.uniform(-300, 300, n // 2)) * rng.choice([-1, 1], n // 2)])
+    a[:8] = [0.0, 1.0, 2.0, 0.5, 1e-310, 4.0, 9.0, 1e308]
+    b[:8] = [3.0, 3.0, 0.1, 0.5, 7.0, 1e-310, 0.001, 1e-5]
+    q = np.empty(n)
+    s = np.empty(n)
+    L = rgp._lib.lib()
+    rgp._lib.check(L.rgs_selftest_math(0, rgp._lib.dptr(a), rgp._lib.dptr(b), n, rgp._lib.dptr(q), rgp._lib.dptr(s)))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(q.view(np.uint64), (a / b).view(np.uint64))
+        assert np.array_equal(s.view(np.uint64), np.sqrt(a).view(np.uint64))
+
+
+def test_reference_sample_values_through_dropin(rgp):
+    """SURVEY.md 8c sample values of the compiled reference, via the GameSim drop-in."""
+    Z = np.zeros(2)
+    sim = rgp.GameSim()
+    assert repr(sim) == "GameSim Object"
+    sim.reset(0.05, 3, np.zeros(4), 0.0, False, "", 0, 0.1, 0.5, 1.0, 0.5)
+    st = sim.run(np.array([1.0, 0.0]), Z, Z, Z)
+    assert st.shape == (22,) and st.dtype == np.float64
+    assert list(st[6:10]) == [float("-2.4975812909820143"), 1.25, float("0.095162581964028339"), 0.0]
+    sim.reset(0.05, 3, np.array([4.5, 0.2, 5.0, 0.0]), 0.0, False, "")          # 6-arg arity (py/run_sim.py:43)
+    st = sim.run(Z, Z, Z, Z)
+    assert list(st[2:6]) == [float("4.7379064549100676"), 0.2, float("4.5241870901798578"), 0.0]
+    st = sim.run(Z, Z, Z, Z)
+    assert list(st[:6]) == [1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    sim.reset(0.05, 3, np.array([4.5, 1.0, 5.0, 0.0]), 0.0, False, "", 0, 0.1, 0.5, 1.0, 0.5)
+    sim.run(Z, Z, Z, Z)
+    st = sim.run(Z, Z, Z, Z)
+    assert list(st[2:6]) == [float("4.6968234197802463"), 1.0, float("-4.093653765390016"), 0.0]
+    sim.reset(0.05, 1, np.array([4.5, 0.2, 5.0, 0.0]), 0.0, False, "", 0, 0.1, 0.5, 1.0, 0.5)
+    sim.run(Z, Z, Z, Z)
+    st1 = sim.run(Z, Z, Z, Z)
+    assert not sim.undecided()
+    st2 = sim.run(np.array([2.0, 2.0]), Z, Z, Z)
+    assert np.array_equal(st1, st2)
+
+
+@pytest.mark.parametrize("n", [2, 1, 3, 4, 7])
+def test_c2_circles_match_oracle(rgp, oracle, n):
+    """BASELINE C2/C3-shaped inputs (dt = 0.01, circle controls), recorded every 50 steps."""
+    from robo_game_py import workloads as w
+    B, K = (1024, 400) if n == 2 else (256, 300)
+    x0, amp, ph = w.c2_inputs(B, n)
+    table = w.circle_controls(amp, ph, w.step_times(K, 0.01))
+    out, ref = run_both(rgp, oracle, n, x0, table, 0.01, rec_every=50)
+    check(out, ref, "c2 n=%d" % n)
+    assert_same(out["time"], np.full(B, ref_time(K, 0.01)), "time")
+
+
+def ref_time(K, dt):
+    t = 0.0
+    for _ in range(K):
+        t += dt
+    return t
+
+
+@pytest.mark.parametrize("n,limit,dt", [(2, 10.0, 0.05), (2, 3.0, 0.01), (4, 10.0, 0.05), (7, 10.0, 0.05)])
+def test_random_hold_controls_match_oracle(rgp, oracle, n, limit, dt):
+    """Collision-rich open-loop play: random piecewise-constant inputs up to input_limit."""
+    from robo_game_py import workloads as w
+    B, K = 512, 400
+    x0, _, _ = w.c2_inputs(B, n, seed=99)
+    table = w.random_hold_controls(2 * n, B, K, limit, hold=20, seed=5 + n)
+    out, ref = run_both(rgp, oracle, n, x0, table, dt, rec_every=100)
+    check(out, ref, "random n=%d" % n)
+    assert ref["stats"]["resolved"] > 1000          # the event pass really ran
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_chase_the_puck_closed_loop(rgp, oracle, n):
+    """Sustained contact (many steps end on the 50-iteration cap), scores change, games end."""
+    from robo_game_py import workloads as w
+    B, K, dt, win = 192, 250, 0.05, 2
+    x0, _, _ = w.c2_inputs(B, n, seed=3)
+    sim = rgp.BatchedGameSim(B, n)
+    state = sim.reset(dt, win, x0)
+    osims = [oracle.OracleGameSim(n) for _ in range(B)]
+    for a, o in enumerate(osims):
+        o.reset(dt, win, x0[:, a])
+    for k in range(K):
+        u = w.chase_controls(state, n)
+        state = sim.run(u)
+        ost = np.stack([o.run(np.ascontiguousarray(u[:, :, a])) for a, o in enumerate(osims)], axis=1)
+        assert_same(state, ost, "chase n=%d step %d" % (n, k))
+    assert_same(sim.undecided(), np.array([o.undecided() for o in osims]), "undecided")
+    assert_same(sim.damage(), np.stack([o.damage() for o in osims], axis=2), "damage")
+    assert_same(sim.time(), np.array([o.time() for o in osims]), "time")
+    caps = sum(o.stats()["cap_hits"] for o in osims)
+    assert sim.counters()["cap_hits"] == caps and caps > 0
+    assert state[:2].sum() > 0                       # somebody scored
+    sim.close()
+
+
+def test_non_default_physics_parameters(rgp, oracle):
+    from robo_game_py import workloads as w
+    B, K, n = 256, 200, 2
+    x0, _, _ = w.c2_inputs(B, n, seed=11)
+    table = w.random_hold_controls(4, B, K, 8.0, hold=10, seed=2)
+    out, ref = run_both(rgp, oracle, n, x0, table, 0.02, win=2, tau_puck=1.0, tau_player=0.3, player_mass=2.0,
+                        puck_mass=0.25)
+    check(out, ref, "physics params")
+
+
+def test_set_state_and_ragged_batch(rgp, oracle):
+    """Batch sizes that do not fill a block / wave, and restart from an arbitrary state."""
+    from robo_game_py import workloads as w
+    n = 2
+    for B in (1, 3, 65, 130):
+        x0, amp, ph = w.c2_inputs(B, n, seed=B)
+        table = w.circle_controls(amp * 2.0, ph, w.step_times(120, 0.05))
+        out, ref = run_both(rgp, oracle, n, x0, table, 0.05)
+        check(out, ref, "ragged B=%d" % B)
+    # restart: run 60 steps, read back, set_state into a fresh sim, run 60 more == 120 straight
+    B = 64
+    x0, amp, ph = w.c2_inputs(B, n, seed=5)
+    table = w.circle_controls(amp * 2.0, ph, w.step_times(120, 0.05))
+    a = rgp.BatchedGameSim(B, n)
+    a.reset(0.05, 1000, x0)
+    mid = a.run_table(table[:60])
+    tmid = a.time()
+    full = a.run_table(table[60:])
+    b = rgp.BatchedGameSim(B, n)
+    b.reset(0.05, 1000, x0)
+    b.set_state(mid, tmid)
+    assert_same(b.run_table(table[60:]), full, "restart")
+    a.close()
+    b.close()
+
+
+def test_full_size_batch_is_shard_invariant(rgp):
+    """BASELINE C2 size (65 536 arenas): arenas are independent, so any sub-range stepped on its
+    own must reproduce its rows of the full batch bit for bit (size-independent property)."""
+    from robo_game_py import workloads as w
+    n, B, K = 2, 65536, 40
+    x0, amp, ph = w.c2_inputs(B, n)
+    t = w.step_times(K, 0.01)
+    big = rgp.BatchedGameSim(B, n)
+    big.reset(0.01, 1000, x0)
+    stride = 4 * 2 * B
+    buf = big.alloc(K * stride)
+    for k0 in range(0, K, 8):
+        buf.upload(w.circle_controls(amp, ph, t[k0:k0 + 8]), offset=k0 * stride)
+    big.step_device(buf, stride, K)
+    full = big.state()
+    buf.free()
+    big.close()
+    for lo, hi in ((0, 1024), (30000, 30257), (65536 - 64, 65536)):
+        sub = rgp.BatchedGameSim(hi - lo, n)
+        sub.reset(0.01, 1000, x0[:, lo:hi])
+        got = sub.run_table(w.circle_controls(amp[:, lo:hi], ph[:, lo:hi], t))
+        assert_same(got, full[:, lo:hi], "shard [%d,%d)" % (lo, hi))
+        sub.close()
+
+
+def test_noise_is_refused_not_faked(rgp):
+    sim = rgp.BatchedGameSim(4, 2)
+    with pytest.raises(rgp.RgsError):
+        sim.reset(0.05, 3, np.zeros(4), 0.1)
+    sim.close()
