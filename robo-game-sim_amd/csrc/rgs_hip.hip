@@ -11,6 +11,7 @@
 #include "../../include/rgs_hip.h"
 #include "gsim_common.hpp"
 #include "gsim_wave.hpp"
+#include "gsim_lane.hpp"
 
 using namespace gsim;
 
@@ -50,6 +51,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   double *G = lds + (wave * GPW + grp) * L::DOUBLES;
   for (int k = 0; k < p.n_steps; ++k)
     arena_step_group<N, GW>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg);
+}
+
+// Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
+// watch fired are then re-run, one at a time, by the whole wave with the grid in LDS
+// (gsim_wave.hpp).  One wave per block: waves never wait for each other, so an arena stuck in
+// a 49-event step only delays the 63 arenas that share its wave.
+template <int N>
+__global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const long long a0 = (long long)blockIdx.x * 64;
+  const long long a = a0 + lane;
+  const bool mine = a < p.B;
+  for (int k = 0; k < p.n_steps; ++k) {
+    const double *ctl = p.ctl + (long long)k * p.ctl_stride;
+    const bool slow = mine && lane_step<N>(p, ctl, a);
+    unsigned long long m = __ballot(slow);
+    __syncthreads();                                 // lane-pass stores visible to the wave pass
+    while (m != 0ull) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1ull;
+      arena_step_group<N, 64>(p, ctl, a0 + bit, lds, lane, 0);
+    }
+    __syncthreads();
+  }
 }
 
 // GameSim::reset on the device (src/GameSim.cpp:27-39); players spawn in rows (n = 2: +-Y/4).
@@ -126,6 +152,16 @@ int launch_wave(rgs_sim *s, const StepArgs &args) {
   return RGS_OK;
 }
 
+template <int N>
+int launch_hybrid(rgs_sim *s, const StepArgs &args) {
+  const long long blocks = (s->B + 63) / 64;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES;
+  hipLaunchKernelGGL((k_step_hybrid<N>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_hybrid launch: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
 int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps) {
   StepArgs a;
   a.dt = s->dt; a.dt_col = s->dt_col;
@@ -137,6 +173,17 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.ctl = ctl_dev; a.ctl_stride = stride; a.n_steps = n_steps;
   a.counters = s->counters;
   a.queue = nullptr; a.queue_count = nullptr;
+  if (s->variant != RGS_VARIANT_WAVE) {
+    switch (s->n) {
+      case 1: return launch_hybrid<1>(s, a);
+      case 2: return launch_hybrid<2>(s, a);
+      case 3: return launch_hybrid<3>(s, a);
+      case 4: return launch_hybrid<4>(s, a);
+      case 5: return launch_hybrid<5>(s, a);
+      case 6: return launch_hybrid<6>(s, a);
+      case 7: return launch_hybrid<7>(s, a);
+    }
+  }
   switch (s->n) {
     case 1: return launch_wave<1>(s, a);
     case 2: return launch_wave<2>(s, a);

@@ -111,14 +111,18 @@ def test_reference_sample_values_through_dropin(rgp):
     assert np.array_equal(st1, st2)
 
 
-@pytest.mark.parametrize("n", [2, 1, 3, 4, 7])
-def test_c2_circles_match_oracle(rgp, oracle, n):
+VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid")]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n", [2, 1, 3, 4, 5, 6, 7])
+def test_c2_circles_match_oracle(rgp, oracle, n, variant):
     """BASELINE C2/C3-shaped inputs (dt = 0.01, circle controls), recorded every 50 steps."""
     from robo_game_py import workloads as w
     B, K = (1024, 400) if n == 2 else (256, 300)
     x0, amp, ph = w.c2_inputs(B, n)
     table = w.circle_controls(amp, ph, w.step_times(K, 0.01))
-    out, ref = run_both(rgp, oracle, n, x0, table, 0.01, rec_every=50)
+    out, ref = run_both(rgp, oracle, n, x0, table, 0.01, rec_every=50, variant=variant)
     check(out, ref, "c2 n=%d" % n)
     assert_same(out["time"], np.full(B, ref_time(K, 0.01)), "time")
 
@@ -130,25 +134,28 @@ def ref_time(K, dt):
     return t
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("n,limit,dt", [(2, 10.0, 0.05), (2, 3.0, 0.01), (4, 10.0, 0.05), (7, 10.0, 0.05)])
-def test_random_hold_controls_match_oracle(rgp, oracle, n, limit, dt):
+def test_random_hold_controls_match_oracle(rgp, oracle, n, limit, dt, variant):
     """Collision-rich open-loop play: random piecewise-constant inputs up to input_limit."""
     from robo_game_py import workloads as w
     B, K = 512, 400
     x0, _, _ = w.c2_inputs(B, n, seed=99)
     table = w.random_hold_controls(2 * n, B, K, limit, hold=20, seed=5 + n)
-    out, ref = run_both(rgp, oracle, n, x0, table, dt, rec_every=100)
+    out, ref = run_both(rgp, oracle, n, x0, table, dt, rec_every=100, variant=variant)
     check(out, ref, "random n=%d" % n)
     assert ref["stats"]["resolved"] > 1000          # the event pass really ran
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("n", [2, 4])
-def test_chase_the_puck_closed_loop(rgp, oracle, n):
+def test_chase_the_puck_closed_loop(rgp, oracle, n, variant):
     """Sustained contact (many steps end on the 50-iteration cap), scores change, games end."""
     from robo_game_py import workloads as w
     B, K, dt, win = 192, 250, 0.05, 2
     x0, _, _ = w.c2_inputs(B, n, seed=3)
     sim = rgp.BatchedGameSim(B, n)
+    sim.set_variant(variant)
     state = sim.reset(dt, win, x0)
     osims = [oracle.OracleGameSim(n) for _ in range(B)]
     for a, o in enumerate(osims):
