@@ -99,13 +99,23 @@ int rgs_timer_start(rgs_sim *sim);
 int rgs_timer_stop(rgs_sim *sim, float *ms_out);
 
 /* Run-time counters summed over arenas since the last reset:
- * out[0] executed arena-steps, [1] events resolved, [2] steps ended by the 50-iteration cap
- * (include/GameSim.h:7), [3] base index past the grid (reference: out-of-bounds write; clamped here),
- * [4] puck events skipped after a goal (src/GameSim.cpp:230-231), [5] arena-steps that took the
- * event pass, [6..7] reserved. */
+ * out[0] events resolved, [1] steps ended by the 50-iteration cap (include/GameSim.h:7),
+ * [2] base index past the grid (reference: out-of-bounds write; clamped here), [3] puck events
+ * skipped after a goal (src/GameSim.cpp:230-231), [4] arena-steps whose first scan found an
+ * event, [5..7] reserved. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
+
+/* The lane pass divides by tau_player / tau_puck with a reciprocal-plus-two-corrections sequence
+ * that is proven and tested to round exactly like IEEE '/'.  enable = 0 forces the
+ * compiler's IEEE division everywhere (slower, same results); taus outside the proof's domain
+ * select it automatically. */
+int rgs_set_fast_division(rgs_sim *sim, int enable);
+
+/* fast[i] = a[i]/tau by the reciprocal sequence, ieee[i] = a[i]/tau by IEEE '/', both on the GPU. */
+int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double tau, double *fast_host,
+                        double *ieee_host);
 
 /* Device arithmetic self-test: computes a[i]/b[i] and sqrt(a[i]) on the GPU with the same
  * code paths the stepper uses, for comparison with the host's IEEE results. */

@@ -32,6 +32,7 @@ enum Counter : int {
 struct StepArgs {
   double dt, dt_col;                 // cpp:27-28
   double tau_player, tau_puck;       // cpp:43-44
+  double inv_tau_player, inv_tau_puck;  // RN(1/tau), host-computed, for div_tau<true>
   double m_player, m_puck;           // cpp:45-46
   double win;                        // winning_score_ as a double (scores are doubles, SimState.h:25)
   long long B;                       // arenas
@@ -67,27 +68,57 @@ struct Chain {
   double p, v;
 };
 
+// a / tau, correctly rounded, for the per-batch constants tau_player / tau_puck.
+//
+// FAST = false: the compiler's IEEE sequence (11 instructions, three of them quarter rate).
+// FAST = true : reciprocal multiply plus two Markstein corrections, 5 full-rate instructions:
+//     q0 = RN(a*y)            y = RN(1/tau) from the host
+//     r0 = RN(a - tau*q0)     q1 = RN(q0 + r0*y)      -> |q1 - a/tau| <= (1/2 + 2^-51) ulp
+//     r1 =    a - tau*q1      q2 = RN(q1 + r1*y)      (r1 exact: q1 is faithful)
+//   q2's pre-rounding value is a/tau + (a/tau - q1)*eps with |eps| <= B*2^-106 (B = tau's 53-bit
+//   significand), i.e. closer to a/tau than any rounding boundary can be (a quotient of two
+//   53-bit numbers stays >= 1/(B*2^53) away from every midpoint) as long as B is not within a
+//   few units of 2^53 - 1; so q2 = RN(a/tau).  Preconditions, enforced by the callers:
+//   tau normal with 2^-100 <= |tau| <= 2^100 and a significand not ending in all ones (host,
+//   fast_division_ok); a == 0 or 2^-760 <= |a| <= 2^520 so r1 never underflows (lane_step's
+//   entry guard).  DESIGN.md "Division by tau" has the full argument; rgs_selftest_divtau and
+//   tests/test_gpu_parity.py check it against IEEE '/' on adversarial near-midpoint inputs.
+template <bool FAST>
+__device__ __forceinline__ double div_tau(double a, double tau, double inv) {
+  if (FAST) {
+    const double q0 = a * inv;
+    const double r0 = __builtin_fma(-tau, q0, a);
+    const double q1 = __builtin_fma(r0, inv, q0);
+    const double r1 = __builtin_fma(-tau, q1, a);
+    return __builtin_fma(r1, inv, q1);
+  }
+  return a / tau;
+}
+
 // RK4_player / RK4_puck (src/GameSim.cpp:70-88, 98-116) restricted to one axis.
 //   f(x) = (v, (u - coef*v)/tau): coef = 1 for players (cpp:66-67 with sigma = 0;
 //   1.0*v is exact), 0.2 for the puck (cpp:94-95, whose u is always 0).
 // The position rows of x2..x4 never feed f, so only their velocity rows exist here.
-__device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double tau, double h) {
+// cpp:87 combines x + (k1 + k2*2 + k3*2 + k4)*(dt/6); k*2 is exact, so fma(k, 2, acc) rounds
+// exactly once like the reference's multiply-then-add and is bit-identical to it.
+template <bool FAST>
+__device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double tau, double inv, double h) {
   const double half = h / 2.0;
   const double k1p = x.v;
-  const double k1v = div_ieee(u - coef * x.v, tau);
+  const double k1v = div_tau<FAST>(u - coef * x.v, tau, inv);
   const double x2v = x.v + k1v * half;
   const double k2p = x2v;
-  const double k2v = div_ieee(u - coef * x2v, tau);
+  const double k2v = div_tau<FAST>(u - coef * x2v, tau, inv);
   const double x3v = x.v + k2v * half;
   const double k3p = x3v;
-  const double k3v = div_ieee(u - coef * x3v, tau);
+  const double k3v = div_tau<FAST>(u - coef * x3v, tau, inv);
   const double x4v = x.v + k3v * h;
   const double k4p = x4v;
-  const double k4v = div_ieee(u - coef * x4v, tau);
+  const double k4v = div_tau<FAST>(u - coef * x4v, tau, inv);
   const double w = h / 6.0;
   Chain r;
-  r.p = x.p + (((k1p + k2p * 2.0) + k3p * 2.0) + k4p) * w;   // cpp:87
-  r.v = x.v + (((k1v + k2v * 2.0) + k3v * 2.0) + k4v) * w;
+  r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;   // cpp:87
+  r.v = x.v + (__builtin_fma(k3v, 2.0, __builtin_fma(k2v, 2.0, k1v)) + k4v) * w;
   return r;
 }
 

@@ -25,7 +25,19 @@ namespace gsim {
 // orders of magnitude to spare (rounding moves these quantities by ~1e-16 relative).
 constexpr double kWatchSlack = 1.0e-9;
 
-template <int N>
+// Magnitude window in which div_tau<true>'s residuals stay normal numbers (see its comment).
+// u is held for the step; v only moves by factors >= 0.27 per sub-step (|R(z)| of RK4), so an
+// entry check covers all 50 sub-steps: u == 0 or |u| >= 2^-700, and if u == 0 then v == 0 or
+// |v| >= 2^-600; everything <= 2^500.  Anything else is handed to the exact wave pass.
+__device__ __forceinline__ bool fast_division_safe(double u, double v) {
+  const double lo_u = 0x1.0p-700, lo_v = 0x1.0p-600, hi = 0x1.0p500;
+  const double au = __builtin_fabs(u), av = __builtin_fabs(v);
+  const bool u_ok = (u == 0.0) || (au >= lo_u);
+  const bool v_ok = (au >= lo_u) || (v == 0.0) || (av >= lo_v);
+  return u_ok && v_ok && (au <= hi) && (av <= hi);
+}
+
+template <int N, bool FAST>
 __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__restrict__ ctl, long long a) {
   constexpr int P = 2 * N, E = P + 1, PK = P;
   const long long B = p.B;
@@ -51,13 +63,19 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
 
   const double dt_col = p.dt_col;
   bool watch = false;
+  if (FAST) {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      watch |= !fast_division_safe(ux[e], cx[e].v) || !fast_division_safe(uy[e], cy[e].v);
+  }
   for (int i = 1; i <= kGrid; ++i) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const double coef = e == PK ? 0.2 : 1.0;
       const double tau = e == PK ? p.tau_puck : p.tau_player;
-      cx[e] = rk4_axis(cx[e], ux[e], coef, tau, dt_col);
-      cy[e] = rk4_axis(cy[e], uy[e], coef, tau, dt_col);
+      const double inv = e == PK ? p.inv_tau_puck : p.inv_tau_player;
+      cx[e] = rk4_axis<FAST>(cx[e], ux[e], coef, tau, inv, dt_col);
+      cy[e] = rk4_axis<FAST>(cy[e], uy[e], coef, tau, inv, dt_col);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -70,7 +88,7 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
         const double rsum = rad + (o == PK ? kRPuck : kRPlayer);
         const double r2 = rsum * rsum * (1.0 + kWatchSlack);
         const double dx = cx[e].p - cx[o].p, dy = cy[e].p - cy[o].p;
-        watch |= !(dx * dx + dy * dy > r2);
+        watch |= !(__builtin_fma(dy, dy, dx * dx) > r2);     // the watch is conservative: fma is fine here
       }
     }
   }

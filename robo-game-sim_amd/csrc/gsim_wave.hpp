@@ -210,7 +210,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     G[4 * e + ax] = x.p;
     G[4 * e + 2 + ax] = x.v;
     for (int i = 1; i <= kGrid; ++i) {
-      x = rk4_axis(x, u, coef, tau, dt_col);
+      x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col);
       G[i * CS + 4 * e + ax] = x.p;
       G[i * CS + 4 * e + 2 + ax] = x.v;
     }
@@ -257,7 +257,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
         Chain x;
         x.p = G[(base - 1) * CS + 4 * d + ax];
         x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
-        x = rk4_axis(x, u, coef, tau, dt_t);                 // cpp:255-256
+        x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_t);                 // cpp:255-256
         {                                                    // cpp:259-265 (pij not normalised)
           const double po = __shfl_xor(x.p, 2);
           const double pij = first ? po - x.p : x.p - po;
@@ -287,9 +287,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           }
           x.v = x.v - s * dp;
         }
-        x = rk4_axis(x, u, coef, tau, dt_col - dt_t);        // cpp:287-288
+        x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col - dt_t);        // cpp:287-288
         for (int g = base; g <= kGrid; ++g) {
-          if (g > base) x = rk4_axis(x, u, coef, tau, dt_col);   // cpp:294-295
+          if (g > base) x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col);   // cpp:294-295
           {                                                  // correctOverlap(i, j), cpp:581-592
             const double po = __shfl_xor(x.p, 2);
             const double pij = first ? po - x.p : x.p - po;
@@ -318,7 +318,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
         Chain x;
         x.p = G[(base - 1) * CS + 4 * d + ax];
         x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
-        x = rk4_axis(x, u, coef, tau, dt_t);                 // cpp:309
+        x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_t);                 // cpp:309
         if (my_axis) {                                       // cpp:314-317
           if (positive_wall ? (x.v > 0) : (x.v < 0)) x.v *= -1.0;
         }
@@ -327,10 +327,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
         if (goal) {
           x.p = 0.0; x.v = 0.0;                              // cpp:325
         } else {
-          x = rk4_axis(x, u, coef, tau, dt_col - dt_t);      // cpp:331
+          x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col - dt_t);      // cpp:331
         }
         for (int g = base; g <= kGrid; ++g) {
-          if (g > base) x = rk4_axis(x, u, coef, tau, dt_col);   // cpp:338
+          if (g > base) x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col);   // cpp:338
           if (my_axis && !(goal && g == base)) {             // correctOverlap(wall), cpp:594-623
             const double overlap = positive_wall ? (x.p + r_own - wall) : (-x.p + r_own - wall);
             if (overlap > 0) {

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
 // watch fired are then re-run, one at a time, by the whole wave with the grid in LDS
 // (gsim_wave.hpp).  One wave per block: waves never wait for each other, so an arena stuck in
 // a 49-event step only delays the 63 arenas that share its wave.
-template <int N>
+template <int N, bool FAST>
 __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
   const bool mine = a < p.B;
   for (int k = 0; k < p.n_steps; ++k) {
     const double *ctl = p.ctl + (long long)k * p.ctl_stride;
-    const bool slow = mine && lane_step<N>(p, ctl, a);
+    const bool slow = mine && lane_step<N, FAST>(p, ctl, a);
     unsigned long long m = __ballot(slow);
     __syncthreads();                                 // lane-pass stores visible to the wave pass
     while (m != 0ull) {
@@ -109,6 +109,13 @@ __global__ void k_undecided(const double *state, long long B, double win, uint8_
   out[a] = (state[a] < win && state[B + a] < win) ? 1 : 0;
 }
 
+__global__ void k_selftest_divtau(const double *a, long long n, double tau, double inv, double *fast, double *ieee) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fast[i] = div_tau<true>(a[i], tau, inv);
+  ieee[i] = div_tau<false>(a[i], tau, inv);
+}
+
 __global__ void k_selftest(const double *a, const double *b, long long n, double *q, double *s) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -135,6 +142,7 @@ struct rgs_sim {
   // reset() parameters, src/GameSim.cpp:27-46
   double dt = 0.05, dt_col = 0.05 / kGrid, tau_puck = 0.1, tau_player = 0.5, m_player = 1.0, m_puck = 0.5;
   int win = 3, seed = 0;
+  bool fast_div = true;            // cleared by rgs_set_fast_division(0) or by unsuitable taus
 };
 
 namespace {
@@ -152,11 +160,27 @@ int launch_wave(rgs_sim *s, const StepArgs &args) {
   return RGS_OK;
 }
 
+// div_tau<true>'s preconditions on the divisor (gsim_common.hpp): normal, moderate exponent,
+// significand not ending in a run of ones.
+bool fast_division_ok(double tau) {
+  if (!std::isfinite(tau) || tau == 0.0) return false;
+  const double m = std::fabs(tau);
+  if (m < 0x1.0p-100 || m > 0x1.0p100) return false;
+  uint64_t bits;
+  std::memcpy(&bits, &tau, sizeof bits);
+  const uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+  return frac < 0xFFFFFFFFFFFFFull - 64;
+}
+
 template <int N>
 int launch_hybrid(rgs_sim *s, const StepArgs &args) {
   const long long blocks = (s->B + 63) / 64;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES;
-  hipLaunchKernelGGL((k_step_hybrid<N>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  const bool fast = s->fast_div && fast_division_ok(s->tau_player) && fast_division_ok(s->tau_puck);
+  if (fast)
+    hipLaunchKernelGGL((k_step_hybrid<N, true>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  else
+    hipLaunchKernelGGL((k_step_hybrid<N, false>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_hybrid launch: ") + hipGetErrorString(e));
   return RGS_OK;
@@ -166,6 +190,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   StepArgs a;
   a.dt = s->dt; a.dt_col = s->dt_col;
   a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
+  a.inv_tau_player = 1.0 / s->tau_player; a.inv_tau_puck = 1.0 / s->tau_puck;   // host IEEE division
   a.m_player = s->m_player; a.m_puck = s->m_puck;
   a.win = (double)s->win;
   a.B = s->B;
@@ -447,6 +472,33 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
 int rgs_set_variant(rgs_sim *s, int variant) {
   if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_HYBRID) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
+  return RGS_OK;
+}
+
+int rgs_set_fast_division(rgs_sim *s, int enable) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_set_fast_division: null handle");
+  s->fast_div = enable != 0;
+  return RGS_OK;
+}
+
+int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double tau, double *fast_host,
+                        double *ieee_host) {
+  if (!a_host || !fast_host || !ieee_host || n < 1) return fail(RGS_ERR_ARG, "rgs_selftest_divtau: bad argument");
+  if (!fast_division_ok(tau)) return fail(RGS_ERR_UNSUPPORTED, "rgs_selftest_divtau: tau outside the fast-division domain");
+  HIP_TRY(hipSetDevice(device_id));
+  double *a = nullptr, *f = nullptr, *q = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)n;
+  HIP_TRY(hipMalloc(&a, bytes));
+  HIP_TRY(hipMalloc(&f, bytes));
+  HIP_TRY(hipMalloc(&q, bytes));
+  HIP_TRY(hipMemcpy(a, a_host, bytes, hipMemcpyHostToDevice));
+  const int tb = 256;
+  hipLaunchKernelGGL(k_selftest_divtau, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, 0, a, (long long)n, tau,
+                     1.0 / tau, f, q);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(fast_host, f, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ieee_host, q, bytes, hipMemcpyDeviceToHost));
+  hipFree(a); hipFree(f); hipFree(q);
   return RGS_OK;
 }
 

@@ -247,6 +247,9 @@ class BatchedGameSim:
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
 
+    def set_fast_division(self, enable):
+        _lib.check(self._L.rgs_set_fast_division(self._h, int(bool(enable))))
+
     def alloc(self, n_doubles):
         return _DeviceBuffer(self, n_doubles)
 

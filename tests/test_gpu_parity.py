@@ -85,6 +85,86 @@ def test_device_division_and_sqrt_are_ieee(rgp):
         assert np.array_equal(s.view(np.uint64), np.sqrt(a).view(np.uint64))
 
 
+def _near_midpoint_dividends(tau, count, rng):
+    """Doubles a whose quotient a/tau lies as close to a rounding boundary as 53-bit inputs allow:
+    a = round_to_double((q + ulp(q)/2) * tau), both neighbours, for random 53-bit q."""
+    import math
+    mt, et = math.frexp(tau)
+    Bt = int(mt * (1 << 53))                          # tau = Bt * 2^(et-53)
+    out = []
+    for _ in range(count):
+        M = int(rng.integers(1 << 52, 1 << 53))
+        k = int(rng.integers(-40, 40))
+        num = (2 * M + 1) * Bt                        # exact (q + ulp/2) * tau = num * 2^(k-1+et-53)
+        sh = num.bit_length() - 53
+        lo = num >> sh
+        for cand in (lo, lo + 1):
+            out.append(math.ldexp(float(cand), sh + k - 1 + et - 53))
+            out.append(-out[-1])
+    return np.array(out)
+
+
+@pytest.mark.parametrize("tau", [0.1, 0.5, 1.0, 0.3, 0.7, 1.0 / 3.0, 1.9999999, 123.456, 3e-5])
+def test_division_by_tau_rounds_like_ieee(rgp, tau):
+    """div_tau<true> (reciprocal + two Markstein corrections) == IEEE '/' on the device == host '/'."""
+    rng = np.random.default_rng(int(tau * 1e6) % 9973)
+    n = 1 << 21
+    a = np.concatenate([rng.uniform(-12, 12, n // 2), np.exp(rng.uniform(-500, 330, n // 2)) * rng.choice([-1, 1], n // 2),
+                        _near_midpoint_dividends(tau, 20000, rng), [0.0, 1.0, -1.0, tau, 3 * tau, 1e-300 * tau]])
+    a = np.ascontiguousarray(a)
+    fast = np.empty(a.size)
+    ieee = np.empty(a.size)
+    L = rgp._lib.lib()
+    rgp._lib.check(L.rgs_selftest_divtau(0, rgp._lib.dptr(a), a.size, tau, rgp._lib.dptr(fast), rgp._lib.dptr(ieee)))
+    host = a / tau
+    assert np.array_equal(ieee.view(np.uint64), host.view(np.uint64))
+    assert np.array_equal(fast, host), "%d of %d quotients differ" % (int((fast != host).sum()), a.size)
+
+
+def test_fast_and_ieee_division_builds_agree(rgp, oracle):
+    """The same run with the IEEE-division kernel forced gives the same bits."""
+    from robo_game_py import workloads as w
+    n, B, K = 2, 512, 200
+    x0, amp, ph = w.c2_inputs(B, n, seed=21)
+    table = w.circle_controls(amp * 2.5, ph, w.step_times(K, 0.05))
+    res = []
+    for fast in (True, False):
+        sim = rgp.BatchedGameSim(B, n)
+        sim.set_fast_division(fast)
+        sim.reset(0.05, 1000, x0)
+        res.append(sim.run_table(table))
+        sim.close()
+    assert_same(res[0], res[1], "fast vs ieee division")
+    ref = oracle.batch_run(n, x0, table, K, dt=0.05, winning_score=1000, n_threads=8)
+    assert_same(res[0], ref["state"], "fast division vs oracle")
+
+
+def test_tiny_velocities_take_the_exact_path(rgp, oracle):
+    """Puck speeds decaying through 1e-200 .. denormal: outside div_tau<true>'s window, so the lane
+    pass must hand those arenas to the IEEE wave pass; results stay bit-identical."""
+    n, B, K = 2, 64, 30
+    sim = rgp.BatchedGameSim(B, n)
+    sim.reset(0.05, 1000, np.zeros(4))
+    st = sim.state()
+    mags = np.exp(np.linspace(np.log(1e-323), np.log(1e-150), B))
+    st[4] = mags
+    st[5] = -mags[::-1]
+    st[8] = mags * 3.0                                # a player too (u = 0 below)
+    sim.set_state(st, 0.0)
+    ctl = np.zeros((4, 2, B))
+    osims = []
+    for a in range(B):
+        o = oracle.OracleGameSim(n)
+        o.reset(0.05, 1000, np.zeros(4))
+        o.set_state(st[:, a], 0.0)
+        osims.append(o)
+    for k in range(K):
+        got = sim.run(ctl)
+        ref = np.stack([o.run(np.ascontiguousarray(ctl[:, :, a])) for a, o in enumerate(osims)], axis=1)
+        assert np.array_equal(got, ref), "step %d" % k
+    sim.close()
+
+
 def test_reference_sample_values_through_dropin(rgp):
     """SURVEY.md 8c sample values of the compiled reference, via the GameSim drop-in."""
     Z = np.zeros(2)
