@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--cpu-sample-arenas", type=int, default=2048)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg (a 1-GPU box's CPU share)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,6 +89,9 @@ def main():
 
     # ---- inputs, resident in HBM before timing ------------------------------------------
     x0_all, amp_all, ph_all = w.c2_inputs(B * world, n)          # one global ensemble, sliced per rank
+    if args.calm:
+        amp_all = amp_all * 0.05
+        x0_all = x0_all * np.array([0.2, 0.2, 0.05, 0.05])[:, None]
     lo, hi = rank * B, (rank + 1) * B
     x0, amp, ph = x0_all[:, lo:hi], amp_all[:, lo:hi], ph_all[:, lo:hi]
     times = w.step_times(W + K, DT)

@@ -102,7 +102,7 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * out[0] events resolved, [1] steps ended by the 50-iteration cap (include/GameSim.h:7),
  * [2] base index past the grid (reference: out-of-bounds write; clamped here), [3] puck events
  * skipped after a goal (src/GameSim.cpp:230-231), [4] arena-steps whose first scan found an
- * event, [5..7] reserved. */
+ * event, [5] arena-steps the hybrid's lane pass handed to the wave pass, [6..7] reserved. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
 int rgs_set_variant(rgs_sim *sim, int variant);

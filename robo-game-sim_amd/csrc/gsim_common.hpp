@@ -24,7 +24,8 @@ enum Counter : int {
   CNT_CAP_HITS = 1,       // steps ended by the 50-iteration cap
   CNT_BASE_OVERFLOW = 2,  // base index past the grid (clamped)
   CNT_SKIPPED = 3,        // puck events dropped after a goal, cpp:230-231
-  CNT_EVENT_STEPS = 4,    // arena-steps that entered the event pass
+  CNT_EVENT_STEPS = 4,    // arena-steps whose first scan found an event
+  CNT_FLAGGED = 5,        // hybrid: arena-steps the lane pass handed to the wave pass
   CNT_N = 8
 };
 
@@ -34,6 +35,10 @@ struct StepArgs {
   double tau_player, tau_puck;       // cpp:43-44
   double inv_tau_player, inv_tau_puck;  // RN(1/tau), host-computed, for div_tau<true>
   double m_player, m_puck;           // cpp:45-46
+  // Exact sqrt-free overlap tests.  For R = r_a + r_b (pp: two players, pk: player + puck):
+  //   le = max{s : fl(sqrt(s)) <= R}   so  fl(sqrt(s)) <= R   <=>  s <= le   (cpp:471)
+  //   lt = max{s : fl(sqrt(s)) <  R}   so  R - fl(sqrt(s)) > 0 <=>  s <= lt   (cpp:260-261, 584-585)
+  double le_pp, le_pk, lt_pp, lt_pk;
   double win;                        // winning_score_ as a double (scores are doubles, SimState.h:25)
   long long B;                       // arenas
   double *state;                     // [S][B]

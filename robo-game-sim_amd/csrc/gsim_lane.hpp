@@ -25,82 +25,151 @@ namespace gsim {
 // orders of magnitude to spare (rounding moves these quantities by ~1e-16 relative).
 constexpr double kWatchSlack = 1.0e-9;
 
-// Magnitude window in which div_tau<true>'s residuals stay normal numbers (see its comment).
-// u is held for the step; v only moves by factors >= 0.27 per sub-step (|R(z)| of RK4), so an
-// entry check covers all 50 sub-steps: u == 0 or |u| >= 2^-700, and if u == 0 then v == 0 or
-// |v| >= 2^-600; everything <= 2^500.  Anything else is handed to the exact wave pass.
-__device__ __forceinline__ bool fast_division_safe(double u, double v) {
-  const double lo_u = 0x1.0p-700, lo_v = 0x1.0p-600, hi = 0x1.0p500;
-  const double au = __builtin_fabs(u), av = __builtin_fabs(v);
-  const bool u_ok = (u == 0.0) || (au >= lo_u);
-  const bool v_ok = (au >= lo_u) || (v == 0.0) || (av >= lo_v);
-  return u_ok && v_ok && (au <= hi) && (av <= hi);
+// One RK4 sub-step for M independent chains, written stage-major: every statement below is a
+// loop over the chains, so consecutive instructions belong to different chains and a single
+// wave per SIMD (65 536 arenas = 1024 waves = one per SIMD) still issues back to back instead
+// of waiting out each dependent fp64 latency.  Arithmetic per chain is exactly rk4_axis<FAST>.
+// The batch is chains [C0, C0 + M) of the arena's arrays; chains >= PKC belong to the puck.
+template <bool FAST, int C0, int M, int PKC>
+__device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *__restrict__ v_all,
+                                           const double *__restrict__ u_all, double tau_pl, double inv_pl,
+                                           double tau_pk, double inv_pk, double h) {
+  const double half = h / 2.0, w = h / 6.0;
+  double *p = p_all + C0, *v = v_all + C0;
+  const double *u = u_all + C0;
+  double a[M], q[M], r[M], accv[M], accp[M];
+#define GSIM_EACH for (int c = 0; c < M; ++c)
+#define GSIM_TAU(c) ((c) + C0 >= PKC ? tau_pk : tau_pl)
+#define GSIM_INV(c) ((c) + C0 >= PKC ? inv_pk : inv_pl)
+#define GSIM_COEF(c) ((c) + C0 >= PKC ? 0.2 : 1.0)
+#define GSIM_DIV()                                                                      \
+  if (FAST) {                                                                           \
+    _Pragma("unroll") GSIM_EACH q[c] = a[c] * GSIM_INV(c);                              \
+    _Pragma("unroll") GSIM_EACH r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);         \
+    _Pragma("unroll") GSIM_EACH q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);          \
+    _Pragma("unroll") GSIM_EACH r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);         \
+    _Pragma("unroll") GSIM_EACH q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);          \
+  } else {                                                                              \
+    _Pragma("unroll") GSIM_EACH q[c] = a[c] / GSIM_TAU(c);                              \
+  }
+  // k1 = f(x)
+#pragma unroll
+  GSIM_EACH a[c] = u[c] - GSIM_COEF(c) * v[c];
+  GSIM_DIV();
+#pragma unroll
+  GSIM_EACH { accv[c] = q[c]; accp[c] = v[c]; }                       // k1v, k1p
+  // k2 = f(x + k1*h/2)
+#pragma unroll
+  GSIM_EACH r[c] = v[c] + q[c] * half;                                // x2v (= k2p)
+#pragma unroll
+  GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = u[c] - GSIM_COEF(c) * r[c]; }
+  GSIM_DIV();
+#pragma unroll
+  GSIM_EACH accv[c] = __builtin_fma(q[c], 2.0, accv[c]);
+  // k3 = f(x + k2*h/2)
+#pragma unroll
+  GSIM_EACH r[c] = v[c] + q[c] * half;                                // x3v (= k3p)
+#pragma unroll
+  GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = u[c] - GSIM_COEF(c) * r[c]; }
+  GSIM_DIV();
+#pragma unroll
+  GSIM_EACH accv[c] = __builtin_fma(q[c], 2.0, accv[c]);
+  // k4 = f(x + k3*h)
+#pragma unroll
+  GSIM_EACH r[c] = v[c] + q[c] * h;                                   // x4v (= k4p)
+#pragma unroll
+  GSIM_EACH { accp[c] = accp[c] + r[c]; a[c] = u[c] - GSIM_COEF(c) * r[c]; }
+  GSIM_DIV();
+#pragma unroll
+  GSIM_EACH { p[c] = p[c] + accp[c] * w; v[c] = v[c] + (accv[c] + q[c]) * w; }   // cpp:87
+#undef GSIM_DIV
+#undef GSIM_COEF
+#undef GSIM_INV
+#undef GSIM_TAU
+#undef GSIM_EACH
 }
 
+// All M chains of an arena, at most 10 at a time (more would spill registers at 4v4 and up).
+template <bool FAST, int M, int PKC, int C0 = 0>
+__device__ __forceinline__ void rk4_all_chains(double *p, double *v, const double *u, double tau_pl, double inv_pl,
+                                               double tau_pk, double inv_pk, double h) {
+  constexpr int NB = (M + 9) / 10, SZ = (M + NB - 1) / NB;
+  constexpr int MB = (M - C0) < SZ ? (M - C0) : SZ;
+  rk4_chains<FAST, C0, MB, PKC>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
+  if constexpr (C0 + MB < M) rk4_all_chains<FAST, M, PKC, C0 + MB>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
+}
+
+// Chains are numbered c = 2*e + axis: the puck's two chains come last (c >= 2*P).
+// Returns true when the arena must take the wave pass; discmask then holds the discs whose watch
+// fired (all discs when the division guard tripped).
 template <int N, bool FAST>
-__device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__restrict__ ctl, long long a) {
-  constexpr int P = 2 * N, E = P + 1, PK = P;
+__device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__restrict__ ctl, long long a,
+                                          unsigned &discmask) {
+  constexpr int P = 2 * N, E = P + 1, PK = P, M = 2 * E;
   const long long B = p.B;
   const double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
   if (!(TAS < p.win && TBS < p.win)) return false;          // decided: run() is a no-op, cpp:121-123
 
-  Chain cx[E], cy[E];
-  double ux[E], uy[E];
+  double pos[M], vel[M], u[M];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int row = state_row<N>(e);
-    cx[e].p = p.state[(long long)(row + 0) * B + a];
-    cy[e].p = p.state[(long long)(row + 1) * B + a];
-    cx[e].v = p.state[(long long)(row + 2) * B + a];
-    cy[e].v = p.state[(long long)(row + 3) * B + a];
+    pos[2 * e + 0] = p.state[(long long)(row + 0) * B + a];
+    pos[2 * e + 1] = p.state[(long long)(row + 1) * B + a];
+    vel[2 * e + 0] = p.state[(long long)(row + 2) * B + a];
+    vel[2 * e + 1] = p.state[(long long)(row + 3) * B + a];
     if (e != PK) {
-      ux[e] = ctl[(long long)(2 * e + 0) * B + a];
-      uy[e] = ctl[(long long)(2 * e + 1) * B + a];
+      u[2 * e + 0] = ctl[(long long)(2 * e + 0) * B + a];
+      u[2 * e + 1] = ctl[(long long)(2 * e + 1) * B + a];
     } else {
-      ux[e] = 0.0; uy[e] = 0.0;                             // cpp:188
+      u[2 * e + 0] = 0.0; u[2 * e + 1] = 0.0;               // cpp:188
     }
   }
 
   const double dt_col = p.dt_col;
-  bool watch = false;
+  bool guard = false;
+  bool wd[E];                                               // per-disc watch (lane masks live in SGPRs)
+#pragma unroll
+  for (int e = 0; e < E; ++e) wd[e] = false;
   if (FAST) {
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      watch |= !fast_division_safe(ux[e], cx[e].v) || !fast_division_safe(uy[e], cy[e].v);
+    for (int c = 0; c < M; ++c) guard |= !fast_division_safe(u[c], vel[c]);
   }
   for (int i = 1; i <= kGrid; ++i) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const double coef = e == PK ? 0.2 : 1.0;
-      const double tau = e == PK ? p.tau_puck : p.tau_player;
-      const double inv = e == PK ? p.inv_tau_puck : p.inv_tau_player;
-      cx[e] = rk4_axis<FAST>(cx[e], ux[e], coef, tau, inv, dt_col);
-      cy[e] = rk4_axis<FAST>(cy[e], uy[e], coef, tau, inv, dt_col);
-    }
+    rk4_all_chains<FAST, M, 2 * PK>(pos, vel, u, p.tau_player, p.inv_tau_player, p.tau_puck, p.inv_tau_puck, dt_col);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const double rad = e == PK ? kRPuck : kRPlayer;
       const double xthr = kX / 2.0 - rad - kWatchSlack, ythr = kY / 2.0 - rad - kWatchSlack;
       // NaN positions must not slip through as "no overlap": !(x < thr) is true for NaN
-      watch |= !(__builtin_fabs(cx[e].p) < xthr) || !(__builtin_fabs(cy[e].p) < ythr);
+      wd[e] |= !(__builtin_fabs(pos[2 * e]) < xthr) || !(__builtin_fabs(pos[2 * e + 1]) < ythr);
 #pragma unroll
       for (int o = e + 1; o < E; ++o) {
         const double rsum = rad + (o == PK ? kRPuck : kRPlayer);
         const double r2 = rsum * rsum * (1.0 + kWatchSlack);
-        const double dx = cx[e].p - cx[o].p, dy = cy[e].p - cy[o].p;
-        watch |= !(__builtin_fma(dy, dy, dx * dx) > r2);     // the watch is conservative: fma is fine here
+        const double dx = pos[2 * e] - pos[2 * o], dy = pos[2 * e + 1] - pos[2 * o + 1];
+        const bool near = !(__builtin_fma(dy, dy, dx * dx) > r2);   // the watch is conservative: fma is fine here
+        wd[e] |= near;
+        wd[o] |= near;
       }
     }
+  }
+  bool watch = guard;
+  discmask = guard ? ~0u : 0u;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    watch |= wd[e];
+    discmask |= wd[e] ? (1u << e) : 0u;
   }
   if (watch) return true;
 
 #pragma unroll
   for (int e = 0; e < E; ++e) {                             // cpp:153-157
     const int row = state_row<N>(e);
-    p.state[(long long)(row + 0) * B + a] = cx[e].p;
-    p.state[(long long)(row + 1) * B + a] = cy[e].p;
-    p.state[(long long)(row + 2) * B + a] = cx[e].v;
-    p.state[(long long)(row + 3) * B + a] = cy[e].v;
+    p.state[(long long)(row + 0) * B + a] = pos[2 * e + 0];
+    p.state[(long long)(row + 1) * B + a] = pos[2 * e + 1];
+    p.state[(long long)(row + 2) * B + a] = vel[2 * e + 0];
+    p.state[(long long)(row + 3) * B + a] = vel[2 * e + 1];
   }
   p.tcur[a] = p.tcur[a] + p.dt;                             // cpp:158
   return false;

@@ -23,6 +23,39 @@
 
 namespace gsim {
 
+// Exchanges inside an aligned quad of lanes by DPP quad_perm (no LDS round trip).
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double quad_xor1(double x) { return quad_perm<0xB1>(x); }   // lanes [1,0,3,2]
+__device__ __forceinline__ double quad_xor2(double x) { return quad_perm<0x4E>(x); }   // lanes [2,3,0,1]
+__device__ __forceinline__ double quad_lane1(double x) { return quad_perm<0x55>(x); }  // lanes [1,1,1,1]
+
+// Magnitude window in which div_tau<true>'s residuals stay normal numbers (see its comment).
+// u is held for the step; v only moves by factors >= 0.27 per sub-step (|R(z)| of RK4), so one
+// check covers the <= 52 sub-steps that follow it: u == 0 or |u| >= 2^-700, and if u == 0 then
+// v == 0 or |v| >= 2^-600; everything <= 2^500.
+__device__ __forceinline__ bool fast_division_safe(double u, double v) {
+  const double lo_u = 0x1.0p-700, lo_v = 0x1.0p-600, hi = 0x1.0p500;
+  const double au = __builtin_fabs(u), av = __builtin_fabs(v);
+  const bool u_ok = (u == 0.0) || (au >= lo_u);
+  const bool v_ok = (au >= lo_u) || (v == 0.0) || (av >= lo_v);
+  return u_ok && v_ok && (au <= hi) && (av <= hi);
+}
+
+// rk4_axis with the division flavour chosen per chain at run time (FAST kernels only).
+template <bool FAST>
+__device__ __forceinline__ Chain rk4_dyn(Chain x, double u, double coef, double tau, double inv, double h, bool fast) {
+  if (FAST) {
+    if (fast) return rk4_axis<true>(x, u, coef, tau, inv, h);
+  }
+  return rk4_axis<false>(x, u, coef, tau, inv, h);
+}
+
 template <int GW>
 __device__ __forceinline__ unsigned long long group_ballot(bool pred, int gbase) {
   unsigned long long m = __ballot(pred);
@@ -45,9 +78,11 @@ __device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuc
 
 // One column of insertCollisions (cpp:371-498) for disc `id`: the earliest candidate among
 // UP, DOWN, RIGHT, LEFT and the other discs in entity order; strict '<' keeps the first found.
+// The pair test fl(sqrt(s)) <= R (cpp:471) is evaluated as s <= le, le = the largest double whose
+// correctly rounded square root is <= R (host-computed, StepArgs::le_*): same truth value, no sqrt.
 template <int N>
-__device__ __forceinline__ void column_candidate(const double *G, int g, int id, double t0, double dt_col,
-                                                 double &best_t, int &best_j, int &best_kind) {
+__device__ __forceinline__ void column_candidate(const StepArgs &p, const double *G, int g, int id, double t0,
+                                                 double dt_col, double &best_t, int &best_j, int &best_kind) {
   using L = WaveLayout<N>;
   const double *ck = G + g * L::CS;
   const double *cm = G + (g - 1) * L::CS;
@@ -88,7 +123,8 @@ __device__ __forceinline__ void column_candidate(const double *G, int g, int id,
     if (o == id) continue;
     const double rad_o = disc_radius<N>(o);
     const double ddx = kpx - ck[4 * o], ddy = kpy - ck[4 * o + 1];
-    if (sqrt_ieee(ddx * ddx + ddy * ddy) <= rad + rad_o) {   // cpp:471
+    const double le = (id == L::PK || o == L::PK) ? p.le_pk : p.le_pp;
+    if (ddx * ddx + ddy * ddy <= le) {                       // cpp:471
       const double dpx = cm[4 * o] - cm[4 * id], dpy = cm[4 * o + 1] - cm[4 * id + 1];         // cpp:484
       const double dvx = cm[4 * o + 2] - cm[4 * id + 2], dvy = cm[4 * o + 3] - cm[4 * id + 3]; // cpp:485
       const double sigma = rad + rad_o;
@@ -108,7 +144,7 @@ __device__ __forceinline__ void column_candidate(const double *G, int g, int id,
 // insertCollisions' inner loop for one disc (cpp:365-506): first column >= base whose best
 // candidate satisfies t_col - t_ < dt_.  Group-uniform result.
 template <int N, int GW>
-__device__ __forceinline__ bool scan_disc(const double *G, int id, int base, double t0, double dt,
+__device__ __forceinline__ bool scan_disc(const StepArgs &p, const double *G, int id, int base, double t0, double dt,
                                           double dt_col, int lg, int gbase, double &out_t, int &out_j,
                                           int &out_kind) {
   for (int g0 = base; g0 <= kGrid; g0 += GW) {
@@ -117,7 +153,7 @@ __device__ __forceinline__ bool scan_disc(const double *G, int id, int base, dou
     double bt = 1.0e9;
     int bj = -1, bk = -1;
     if (g <= kGrid) {
-      column_candidate<N>(G, g, id, t0, dt_col, bt, bj, bk);
+      column_candidate<N>(p, G, g, id, t0, dt_col, bt, bj, bk);
       hit = (bt - t0 < dt);                                  // cpp:501
     }
     const unsigned long long m = group_ballot<GW>(hit, gbase);
@@ -183,10 +219,12 @@ struct EventSlots {
 
 // Full reference step for arena `a`.  G: this group's LDS region (WaveLayout<N>::DOUBLES).
 // lg: lane index inside the group; gbase: wave lane of the group's lane 0.
+// discmask: discs whose overlap watch fired in the lane pass (all ones when unknown); a disc
+// outside the mask provably has no candidate in the first scan, so that scan is skipped.
 // Returns without touching anything if the game is already decided (cpp:121-123).
-template <int N, int GW>
+template <int N, int GW, bool FAST>
 __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a, double *G,
-                                 int lg, int gbase) {
+                                 int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
   constexpr int E = L::E, PK = L::PK, CS = L::CS;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
@@ -204,13 +242,14 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     Chain x;
     x.p = p.state[(long long)(row + ax) * B + a];
     x.v = p.state[(long long)(row + 2 + ax) * B + a];
-    double u = 0.0, coef = 0.2, tau = p.tau_puck;            // cpp:188: puck input is (0, 0)
-    if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; }
+    double u = 0.0, coef = 0.2, tau = p.tau_puck, inv = p.inv_tau_puck;   // cpp:188: puck input is (0, 0)
+    if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; inv = p.inv_tau_player; }
     U[2 * e + ax] = u;
     G[4 * e + ax] = x.p;
     G[4 * e + 2 + ax] = x.v;
+    const bool fast = FAST && fast_division_safe(u, x.v);
     for (int i = 1; i <= kGrid; ++i) {
-      x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col);
+      x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);
       G[i * CS + 4 * e + ax] = x.p;
       G[i * CS + 4 * e + 2 + ax] = x.v;
     }
@@ -226,7 +265,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
 #pragma unroll
   for (int id = 0; id < E; ++id) {                           // first pass: checks = all discs, cpp:145
     double tt; int jj, kk;
-    if (scan_disc<N, GW>(G, id, base, t0, dt, dt_col, lg, gbase, tt, jj, kk)) ev.put(id, tt, jj, kk, seq++);
+    if (((discmask >> id) & 1u) && scan_disc<N, GW>(p, G, id, base, t0, dt, dt_col, lg, gbase, tt, jj, kk))
+      ev.put(id, tt, jj, kk, seq++);
   }
   counter = 1;
   const bool had_events = ev.any();
@@ -242,43 +282,57 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     if (base < 1) base = 1;
     n_resolved++;
     const double dt_t = ct - (t0 + dt_col * (double)(base - 1));       // cpp:254,308
+    const bool is_pair = ckind == PAIR;
 
-    if (ckind == PAIR) {                                     // cpp:242-299
-      if (lg < 4) {
-        const bool first = lg < 2;                           // lanes 0,1: disc i; lanes 2,3: disc j
-        const int d = first ? ci : cj, ax = lg & 1;
+    // Lanes 0,1 carry disc i (x, y); lanes 2,3 carry disc j for a pair event and a harmless
+    // duplicate of disc i for a wall event, so both kinds share one instruction stream.
+    bool goal = false;
+    if (lg < 4) {
+      const bool first = lg < 2;
+      const int d = (is_pair && !first) ? cj : ci, ax = lg & 1;
+      const double r_own = disc_radius<N>(d);
+      const double u = U[2 * d + ax];
+      const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
+      const double inv = d == PK ? p.inv_tau_puck : p.inv_tau_player;
+      Chain x;
+      x.p = G[(base - 1) * CS + 4 * d + ax];
+      x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
+      bool fast = FAST && fast_division_safe(u, x.v);
+      x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_t, fast);   // cpp:255-256, 309
+
+      // pair constants (unused for walls)
+      const double rsum = disc_radius<N>(ci) + disc_radius<N>(is_pair ? cj : ci);
+      const double lt = (ci == PK || cj == PK) ? p.lt_pk : p.lt_pp;   // s <= lt  <=>  rsum - sqrt(s) > 0
+      // wall constants (unused for pairs)
+      const bool my_axis = (ckind == UP || ckind == DOWN) ? (ax == 1) : (ax == 0);
+      const bool positive_wall = (ckind == UP || ckind == RIGHT);
+      const double wall = (ckind == UP || ckind == DOWN) ? kY / 2.0 : kX / 2.0;
+
+      if (is_pair) {                                         // cpp:242-282
         const int o = first ? cj : ci;
-        const double r_own = disc_radius<N>(d);
-        const double rsum = disc_radius<N>(ci) + disc_radius<N>(cj);
         const double m_i = ci == PK ? p.m_puck : p.m_player, m_j = cj == PK ? p.m_puck : p.m_player;
         const double m_oth = o == PK ? p.m_puck : p.m_player;
-        const double u = U[2 * d + ax];
-        const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
-        Chain x;
-        x.p = G[(base - 1) * CS + 4 * d + ax];
-        x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
-        x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_t);                 // cpp:255-256
         {                                                    // cpp:259-265 (pij not normalised)
-          const double po = __shfl_xor(x.p, 2);
+          const double po = quad_xor2(x.p);
           const double pij = first ? po - x.p : x.p - po;
           const double sq = pij * pij;
-          const double s = sq + __shfl_xor(sq, 1);
-          const double overlap = rsum - sqrt_ieee(s);
-          if (overlap > 0) {
+          const double s = sq + quad_xor1(sq);
+          if (s <= lt) {
+            const double overlap = rsum - sqrt_ieee(s);
             const double c = div_ieee(1.01 * r_own, rsum) * overlap;
             x.p = first ? x.p - c * pij : x.p + c * pij;
           }
         }
         {                                                    // elastic impulse, cpp:268-274
-          const double po = __shfl_xor(x.p, 2), vo = __shfl_xor(x.v, 2);
+          const double po = quad_xor2(x.p), vo = quad_xor2(x.v);
           const double dp = x.p - po, dv = x.v - vo;         // own - other on this axis
           const double pr = dv * dp, sq = dp * dp;
-          const double dot1 = pr + __shfl_xor(pr, 1);
-          const double dot2 = sq + __shfl_xor(sq, 1);
+          const double dot1 = pr + quad_xor1(pr);
+          const double dot2 = sq + quad_xor1(sq);
           const double s = div_ieee(div_ieee(2 * m_oth, m_i + m_j) * dot1, dot2);
           if (ci != PK && cj != PK) {                        // damage, cpp:277-282
             const double dvsq = dv * dv;
-            const double dv_sq = 0.01 * (dvsq + __shfl_xor(dvsq, 1));
+            const double dv_sq = 0.01 * (dvsq + quad_xor1(dvsq));
             if (lg == 0) {
               constexpr int Pn = L::P;
               p.damage[(long long)(ci * Pn + cj) * B + a] += m_i * dv_sq;
@@ -287,74 +341,56 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           }
           x.v = x.v - s * dp;
         }
-        x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col - dt_t);        // cpp:287-288
-        for (int g = base; g <= kGrid; ++g) {
-          if (g > base) x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col);   // cpp:294-295
-          {                                                  // correctOverlap(i, j), cpp:581-592
-            const double po = __shfl_xor(x.p, 2);
-            const double pij = first ? po - x.p : x.p - po;
-            const double sq = pij * pij;
-            const double s = sq + __shfl_xor(sq, 1);
-            const double overlap = rsum - sqrt_ieee(s);
-            if (overlap > 0) {
-              const double c = div_ieee(1.1 * r_own, rsum) * overlap;
-              x.p = first ? x.p - c * pij : x.p + c * pij;
-            }
-          }
-          G[g * CS + 4 * d + ax] = x.p;
-          G[g * CS + 4 * d + 2 + ax] = x.v;
-        }
-      }
-    } else {                                                 // wall, cpp:300-343
-      bool goal = false;
-      if (lg < 2) {
-        const int d = ci, ax = lg;
-        const double r_own = disc_radius<N>(d);
-        const double u = U[2 * d + ax];
-        const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
-        const bool my_axis = (ckind == UP || ckind == DOWN) ? (ax == 1) : (ax == 0);
-        const bool positive_wall = (ckind == UP || ckind == RIGHT);
-        const double wall = (ckind == UP || ckind == DOWN) ? kY / 2.0 : kX / 2.0;
-        Chain x;
-        x.p = G[(base - 1) * CS + 4 * d + ax];
-        x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
-        x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_t);                 // cpp:309
+      } else {                                               // wall, cpp:300-327
         if (my_axis) {                                       // cpp:314-317
           if (positive_wall ? (x.v > 0) : (x.v < 0)) x.v *= -1.0;
         }
-        const double py = __shfl(x.p, gbase + 1);
+        const double py = quad_lane1(x.p);
         goal = d == PK && (ckind == LEFT || ckind == RIGHT) && py < kGoalH / 2.0 && py > -kGoalH / 2.0;  // cpp:321-322
-        if (goal) {
-          x.p = 0.0; x.v = 0.0;                              // cpp:325
-        } else {
-          x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col - dt_t);      // cpp:331
-        }
-        for (int g = base; g <= kGrid; ++g) {
-          if (g > base) x = rk4_axis<false>(x, u, coef, tau, 0.0, dt_col);   // cpp:338
-          if (my_axis && !(goal && g == base)) {             // correctOverlap(wall), cpp:594-623
-            const double overlap = positive_wall ? (x.p + r_own - wall) : (-x.p + r_own - wall);
-            if (overlap > 0) {
-              const double c = 1.1 * overlap;
-              x.p = positive_wall ? x.p - c : x.p + c;
-            }
+      }
+      fast = FAST && fast_division_safe(u, x.v);             // the velocity just changed
+      if (goal) {
+        x.p = 0.0; x.v = 0.0;                                // cpp:325
+      } else {
+        x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col - dt_t, fast);   // cpp:287-288, 331
+      }
+      for (int g = base; g <= kGrid; ++g) {
+        if (g > base) x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);   // cpp:294-295, 338
+        if (is_pair) {                                       // correctOverlap(i, j), cpp:581-592
+          const double po = quad_xor2(x.p);
+          const double pij = first ? po - x.p : x.p - po;
+          const double sq = pij * pij;
+          const double s = sq + quad_xor1(sq);
+          if (s <= lt) {
+            const double overlap = rsum - sqrt_ieee(s);
+            const double c = div_ieee(1.1 * r_own, rsum) * overlap;
+            x.p = first ? x.p - c * pij : x.p + c * pij;
           }
+        } else if (my_axis && !(goal && g == base)) {        // correctOverlap(wall), cpp:594-623
+          const double overlap = positive_wall ? (x.p + r_own - wall) : (-x.p + r_own - wall);
+          if (overlap > 0) {
+            const double c = 1.1 * overlap;
+            x.p = positive_wall ? x.p - c : x.p + c;
+          }
+        }
+        if (is_pair || first) {
           G[g * CS + 4 * d + ax] = x.p;
           G[g * CS + 4 * d + 2 + ax] = x.v;
         }
       }
-      goal = __shfl(goal ? 1 : 0, gbase) != 0;
-      if (goal) {                                            // cpp:324-326
-        if (!scored) { if (ckind == RIGHT) TAS += 1.0; else TBS += 1.0; }
-        scored = true;
-      }
+    }
+    goal = __shfl(goal ? 1 : 0, gbase) != 0;
+    if (goal) {                                              // cpp:324-326
+      if (!scored) { if (ckind == RIGHT) TAS += 1.0; else TBS += 1.0; }
+      scored = true;
     }
     wave_sync();
 
     ev.purge(ci, cj);                                        // cpp:347-352
     {                                                        // re-scan i_ then j_, cpp:355-357 -> 147
       double tt; int jj, kk;
-      if (scan_disc<N, GW>(G, ci, base, t0, dt, dt_col, lg, gbase, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
-      if (cj >= 0 && scan_disc<N, GW>(G, cj, base, t0, dt, dt_col, lg, gbase, tt, jj, kk))
+      if (scan_disc<N, GW>(p, G, ci, base, t0, dt, dt_col, lg, gbase, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
+      if (cj >= 0 && scan_disc<N, GW>(p, G, cj, base, t0, dt, dt_col, lg, gbase, tt, jj, kk))
         ev.put(cj, tt, jj, kk, seq++);
     }
   }

@@ -39,7 +39,7 @@ constexpr int kWavesPerBlock = 4;
 
 // One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
 // the SoA arrays (L2-resident) between steps.
-template <int N, int GW>
+template <int N, int GW, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
@@ -50,29 +50,50 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   if (a >= p.B) return;
   double *G = lds + (wave * GPW + grp) * L::DOUBLES;
   for (int k = 0; k < p.n_steps; ++k)
-    arena_step_group<N, GW>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg);
+    arena_step_group<N, GW, FAST>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, ~0u);
 }
 
 // Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
 // watch fired are then re-run, one at a time, by the whole wave with the grid in LDS
 // (gsim_wave.hpp).  One wave per block: waves never wait for each other, so an arena stuck in
 // a 49-event step only delays the 63 arenas that share its wave.
+// Lane-group width of the hybrid's wave pass: the narrowest power of two that holds the 2E
+// (disc, axis) chains, so 4 (n <= 3) or 2 (n >= 4) flagged arenas are re-run side by side.
+template <int N>
+struct HybridGroups {
+  static constexpr int GW = (2 * (2 * N + 1) <= 16) ? 16 : 32;
+  static constexpr int GPW = 64 / GW;
+};
+
 template <int N, bool FAST>
 __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
   extern __shared__ double lds[];
+  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   const int lane = threadIdx.x;
+  const int grp = lane / GW, lg = lane % GW;
   const long long a0 = (long long)blockIdx.x * 64;
   const long long a = a0 + lane;
   const bool mine = a < p.B;
+  double *G = lds + grp * WaveLayout<N>::DOUBLES;
   for (int k = 0; k < p.n_steps; ++k) {
     const double *ctl = p.ctl + (long long)k * p.ctl_stride;
-    const bool slow = mine && lane_step<N, FAST>(p, ctl, a);
+    unsigned discmask = 0u;
+    const bool slow = mine && lane_step<N, FAST>(p, ctl, a, discmask);
     unsigned long long m = __ballot(slow);
+    if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
     __syncthreads();                                 // lane-pass stores visible to the wave pass
-    while (m != 0ull) {
-      const int bit = __builtin_ctzll(m);
-      m &= m - 1ull;
-      arena_step_group<N, 64>(p, ctl, a0 + bit, lds, lane, 0);
+    while (m != 0ull) {                              // GPW flagged arenas per round, one per lane group
+      int bit = -1;
+      unsigned long long mm = m;
+#pragma unroll
+      for (int i = 0; i < GPW; ++i) {
+        const int b = mm != 0ull ? __builtin_ctzll(mm) : -1;
+        if (i == grp) bit = b;
+        mm &= mm - 1ull;                             // 0 & anything stays 0
+      }
+      m = mm;
+      const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
+      if (bit >= 0) arena_step_group<N, GW, FAST>(p, ctl, a0 + bit, G, lg, lane - lg, dm);
     }
     __syncthreads();
   }
@@ -147,19 +168,6 @@ struct rgs_sim {
 
 namespace {
 
-template <int N>
-int launch_wave(rgs_sim *s, const StepArgs &args) {
-  constexpr int GW = 64;
-  constexpr int GPW = 64 / GW;
-  const long long per_block = (long long)kWavesPerBlock * GPW;
-  const long long blocks = (s->B + per_block - 1) / per_block;
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * per_block;
-  hipLaunchKernelGGL((k_step_wave<N, GW>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave launch: ") + hipGetErrorString(e));
-  return RGS_OK;
-}
-
 // div_tau<true>'s preconditions on the divisor (gsim_common.hpp): normal, moderate exponent,
 // significand not ending in a run of ones.
 bool fast_division_ok(double tau) {
@@ -172,11 +180,40 @@ bool fast_division_ok(double tau) {
   return frac < 0xFFFFFFFFFFFFFull - 64;
 }
 
+bool use_fast_division(const rgs_sim *s) {
+  return s->fast_div && fast_division_ok(s->tau_player) && fast_division_ok(s->tau_puck);
+}
+
+// Largest double s with fl(sqrt(s)) <= R (strict = false) or < R (strict = true); host sqrt is IEEE.
+double sqrt_threshold(double R, bool strict) {
+  auto ok = [&](double s) { const double r = std::sqrt(s); return strict ? r < R : r <= R; };
+  double s = R * R;
+  while (!ok(s)) s = std::nextafter(s, 0.0);
+  while (ok(std::nextafter(s, INFINITY))) s = std::nextafter(s, INFINITY);
+  return s;
+}
+
+template <int N>
+int launch_wave(rgs_sim *s, const StepArgs &args) {
+  constexpr int GW = 64;
+  constexpr int GPW = 64 / GW;
+  const long long per_block = (long long)kWavesPerBlock * GPW;
+  const long long blocks = (s->B + per_block - 1) / per_block;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * per_block;
+  if (use_fast_division(s))
+    hipLaunchKernelGGL((k_step_wave<N, GW, true>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  else
+    hipLaunchKernelGGL((k_step_wave<N, GW, false>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave launch: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
 template <int N>
 int launch_hybrid(rgs_sim *s, const StepArgs &args) {
   const long long blocks = (s->B + 63) / 64;
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES;
-  const bool fast = s->fast_div && fast_division_ok(s->tau_player) && fast_division_ok(s->tau_puck);
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
+  const bool fast = use_fast_division(s);
   if (fast)
     hipLaunchKernelGGL((k_step_hybrid<N, true>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
   else
@@ -192,6 +229,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
   a.inv_tau_player = 1.0 / s->tau_player; a.inv_tau_puck = 1.0 / s->tau_puck;   // host IEEE division
   a.m_player = s->m_player; a.m_puck = s->m_puck;
+  a.le_pp = sqrt_threshold(kRPlayer + kRPlayer, false); a.le_pk = sqrt_threshold(kRPlayer + kRPuck, false);
+  a.lt_pp = sqrt_threshold(kRPlayer + kRPlayer, true);  a.lt_pk = sqrt_threshold(kRPlayer + kRPuck, true);
   a.win = (double)s->win;
   a.B = s->B;
   a.state = s->state; a.tcur = s->tcur; a.damage = s->damage;

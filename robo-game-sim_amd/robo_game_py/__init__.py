@@ -241,8 +241,8 @@ class BatchedGameSim:
     def counters(self):
         out = (C.c_int64 * 8)()
         _lib.check(self._L.rgs_get_counters(self._h, out))
-        names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps"]
-        return dict(zip(names, list(out)[:5]))
+        names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps", "flagged"]
+        return dict(zip(names, list(out)[:6]))
 
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
