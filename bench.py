@@ -111,7 +111,7 @@ def main():
     sim = rgp.BatchedGameSim(B, n, device=local_rank)
     sim.set_variant(args.variant)
     sim.reset(DT, 1000000, np.ascontiguousarray(x0))
-    gathered = torch.empty((world, S, B), dtype=torch.float64, device=dev) if world > 1 else None
+    from robo_game_py.ensemble import all_gather_states
     mine = torch.empty((S, B), dtype=torch.float64, device=dev)
 
     def run_steps(k_begin, k_count):
@@ -140,7 +140,7 @@ def main():
     if world > 1:                                # the job's only collective: final states to every rank
         sim.copy_state_to(mine.data_ptr())
         sim.sync()
-        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+        gathered = all_gather_states(mine, B * world)          # (S, B*world) on every rank
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

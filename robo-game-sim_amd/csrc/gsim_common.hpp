@@ -3,7 +3,9 @@
 // Arithmetic contract: IEEE binary64, one rounding per operation, in the
 // association order of the reference (src/GameSim.cpp); the translation unit is
 // compiled with -ffp-contract=off so hipcc forms no FMA from a*b+c.  Explicit
-// __builtin_fma calls appear only inside div_by() (a correctly rounded quotient).
+// __builtin_fma calls appear only where they are bit-identical to the reference's
+// separate operations: div_tau<true> (a correctly rounded quotient) and k*2+acc
+// (k*2 is exact), plus the conservative overlap watch of the lane pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

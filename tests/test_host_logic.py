@@ -1,0 +1,76 @@
+"""Host-side mirror of the reference interface: argument handling, log record, layouts."""
+import struct
+
+import numpy as np
+import pytest
+
+
+def test_reset_accepts_the_arities_the_reference_callers_use(rgp):
+    # py/run_sim.py:43 passes 6 positionals, py/MonteCarlo.py:28-30 passes 11
+    x0 = np.array([-1.0, 0, 0, 0])
+    a6 = rgp.reset_arguments(0.05, 4, x0, 0.0, True, "minimal_game.log")
+    assert a6["seed"] == 0 and a6["tau_puck"] == 0.1 and a6["tau_player"] == 0.5
+    assert a6["player_mass"] == 1.0 and a6["puck_mass"] == 0.5 and a6["log"] is True
+    a11 = rgp.reset_arguments(0.05, 4, x0, 0.0, True, "mc_run_1.log", 1, 0.1, 0.5, 1.0, 0.5)
+    assert a11["seed"] == 1 and a11["logname"] == "mc_run_1.log"
+    d = rgp.reset_arguments()                        # C++ defaults, src/GameSim.cpp:21-25
+    assert (d["dt"], d["winning_score"], d["noise"], d["log"], d["logname"]) == (0.05, 3, 0.0, False, "~/gamelog.log")
+    with pytest.raises(TypeError):
+        rgp.reset_arguments(*range(12))
+    with pytest.raises(TypeError):
+        rgp.reset_arguments(0.05, dt=0.01)
+    with pytest.raises(TypeError):
+        rgp.reset_arguments(bogus=1)
+
+
+def test_log_record_layout_matches_reference_bytes(rgp):
+    # src/GameSim.cpp:161-170: t, TAS, TBS, puck xy, A1 xy, A2 xy, B1 xy, B2 xy, then four 4-double
+    # blocks starting at flat column-major offsets 0,1,2,3 of the 4x4 damage matrix (utils.h:75).
+    state = np.arange(22, dtype=np.float64) + 100
+    dmg = np.arange(16, dtype=np.float64).reshape(4, 4)     # dmg[r, c] = 4r + c
+    rec = rgp.log_record(1.25, state, dmg)
+    vals = struct.unpack("=29d", rec)
+    assert vals[:3] == (1.25, 100.0, 101.0)
+    assert vals[3:5] == (102.0, 103.0)
+    assert vals[5:13] == (106.0, 107.0, 110.0, 111.0, 114.0, 115.0, 118.0, 119.0)
+    flat = dmg.flatten(order="F")
+    assert vals[13:17] == tuple(flat[0:4])           # "row 0" = column 0
+    assert vals[17:21] == tuple(flat[1:5])           # "row 1" = flat elements 1..4
+    assert vals[25:29] == tuple(flat[3:7])
+
+
+def test_state_view_offsets_match_reference_simstate(rgp):
+    # py/src/SimState.py:6-12
+    v = rgp.SimStateView(np.arange(22.0))
+    assert (v.offset("A", 1), v.offset("A", 2), v.offset("B", 1), v.offset("B", 2)) == (6, 10, 14, 18)
+    assert list(v.get_puck_state()) == [2, 3, 4, 5]
+    assert list(v.get_player_state("B", 2)) == [18, 19, 20, 21]
+    v7 = rgp.SimStateView(np.arange(62.0), 7)
+    assert v7.offset("B", 1) == 6 + 4 * 7
+
+
+def test_workloads_are_deterministic_and_shaped(rgp):
+    from robo_game_py import workloads as w
+    x0, amp, ph = w.c2_inputs(32, 2)
+    x0b, ampb, phb = w.c2_inputs(32, 2)
+    assert np.array_equal(x0, x0b) and np.array_equal(amp, ampb) and np.array_equal(ph, phb)
+    assert x0.shape == (4, 32) and amp.shape == (4, 32)
+    t = w.step_times(5, 0.01)
+    assert t[0] == 0.0 and t[3] == 0.01 + 0.01 + 0.01
+    tab = w.circle_controls(amp, ph, t)
+    assert tab.shape == (5, 4, 2, 32) and tab.flags["C_CONTIGUOUS"]
+    assert np.allclose(np.hypot(tab[:, :, 0], tab[:, :, 1]), amp[None])
+    m = w.mindless_controls(4, 3, t)
+    assert m.shape == (5, 4, 2, 3) and m[2, 1, 0, 2] == np.cos(t[2])
+    r = w.random_hold_controls(4, 8, 45, 3.0, hold=20)
+    assert r.shape == (45, 4, 2, 8) and np.abs(r).max() <= 3.0 and np.array_equal(r[0], r[19]) and not np.array_equal(r[19], r[20])
+
+
+def test_partition_covers_everything_once(rgp):
+    from robo_game_py.ensemble import partition
+    for n, w_ in ((10, 3), (65536 * 8, 8), (7, 8), (1, 1)):
+        parts = partition(n, w_)
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w_ - 1))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1
