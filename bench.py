@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--cpu-sample-arenas", type=int, default=2048)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg (a 1-GPU box's CPU share)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path on a single GPU)")
+    ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
     args = ap.parse_args()
 
@@ -76,9 +79,14 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the stepper has no CPU path")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import robo_game_py as rgp
     from robo_game_py import workloads as w
@@ -126,7 +134,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
         sim.sync()
 
@@ -140,11 +148,12 @@ def main():
     if world > 1:                                # the job's only collective: final states to every rank
         sim.copy_state_to(mine.data_ptr())
         sim.sync()
-        gathered = all_gather_states(mine, B * world)          # (S, B*world) on every rank
+        src = mine if args.backend == "nccl" else mine.cpu()
+        gathered = all_gather_states(src, B * world)           # (S, B*world) on every rank
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
