@@ -29,8 +29,10 @@ constexpr double kWatchSlack = 1.0e-9;
 // loop over the chains, so consecutive instructions belong to different chains and a single
 // wave per SIMD (65 536 arenas = 1024 waves = one per SIMD) still issues back to back instead
 // of waiting out each dependent fp64 latency.  Arithmetic per chain is exactly rk4_axis<FAST>.
+enum DivMode : int { DIV_IEEE = 0, DIV_MARKSTEIN = 1, DIV_PLAYER_POW2 = 2 };
+
 // The batch is chains [C0, C0 + M) of the arena's arrays; chains >= PKC belong to the puck.
-template <bool FAST, int C0, int M, int PKC>
+template <int MODE, int C0, int M, int PKC>
 __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *__restrict__ v_all,
                                            const double *__restrict__ u_all, double tau_pl, double inv_pl,
                                            double tau_pk, double inv_pk, double h) {
@@ -42,15 +44,27 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #define GSIM_TAU(c) ((c) + C0 >= PKC ? tau_pk : tau_pl)
 #define GSIM_INV(c) ((c) + C0 >= PKC ? inv_pk : inv_pl)
 #define GSIM_COEF(c) ((c) + C0 >= PKC ? 0.2 : 1.0)
-#define GSIM_DIV()                                                                      \
-  if (FAST) {                                                                           \
-    _Pragma("unroll") GSIM_EACH q[c] = a[c] * GSIM_INV(c);                              \
-    _Pragma("unroll") GSIM_EACH r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);         \
-    _Pragma("unroll") GSIM_EACH q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);          \
-    _Pragma("unroll") GSIM_EACH r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);         \
-    _Pragma("unroll") GSIM_EACH q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);          \
-  } else {                                                                              \
-    _Pragma("unroll") GSIM_EACH q[c] = a[c] / GSIM_TAU(c);                              \
+#define GSIM_IS_PK(c) ((c) + C0 >= PKC)
+// Division of every chain's a[] by its tau, by compile-time mode:
+//   DIV_IEEE      IEEE '/' everywhere (taus outside div_tau<true>'s domain, or forced)
+//   DIV_MARKSTEIN div_tau<true>'s five steps for every chain
+//   DIV_PLAYER_POW2  tau_player is +-2^k (the default 0.5): a/tau = a*(1/tau) exactly -- scaling by a
+//                 power of two is exact and rounds like '/' even into the denormals -- so the 2P
+//                 player chains need one multiply; the puck chains use the five steps.
+#define GSIM_DIV_MARK(COND)                                                                          \
+  _Pragma("unroll") GSIM_EACH if (COND) q[c] = a[c] * GSIM_INV(c);                                    \
+  _Pragma("unroll") GSIM_EACH if (COND) r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);               \
+  _Pragma("unroll") GSIM_EACH if (COND) q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);                \
+  _Pragma("unroll") GSIM_EACH if (COND) r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);               \
+  _Pragma("unroll") GSIM_EACH if (COND) q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);
+#define GSIM_DIV()                                                                                    \
+  if (MODE == DIV_PLAYER_POW2) {                                                                      \
+    _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c] * inv_pl;                             \
+    GSIM_DIV_MARK(GSIM_IS_PK(c))                                                                      \
+  } else if (MODE == DIV_MARKSTEIN) {                                                                 \
+    GSIM_DIV_MARK(true)                                                                               \
+  } else {                                                                                            \
+    _Pragma("unroll") GSIM_EACH q[c] = a[c] / GSIM_TAU(c);                                            \
   }
   // k1 = f(x)
 #pragma unroll
@@ -83,6 +97,8 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #pragma unroll
   GSIM_EACH { p[c] = p[c] + accp[c] * w; v[c] = v[c] + (accv[c] + q[c]) * w; }   // cpp:87
 #undef GSIM_DIV
+#undef GSIM_DIV_MARK
+#undef GSIM_IS_PK
 #undef GSIM_COEF
 #undef GSIM_INV
 #undef GSIM_TAU
@@ -90,19 +106,19 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 }
 
 // All M chains of an arena, at most 10 at a time (more would spill registers at 4v4 and up).
-template <bool FAST, int M, int PKC, int C0 = 0>
+template <int MODE, int M, int PKC, int C0 = 0>
 __device__ __forceinline__ void rk4_all_chains(double *p, double *v, const double *u, double tau_pl, double inv_pl,
                                                double tau_pk, double inv_pk, double h) {
   constexpr int NB = (M + 9) / 10, SZ = (M + NB - 1) / NB;
   constexpr int MB = (M - C0) < SZ ? (M - C0) : SZ;
-  rk4_chains<FAST, C0, MB, PKC>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
-  if constexpr (C0 + MB < M) rk4_all_chains<FAST, M, PKC, C0 + MB>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
+  rk4_chains<MODE, C0, MB, PKC>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
+  if constexpr (C0 + MB < M) rk4_all_chains<MODE, M, PKC, C0 + MB>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
 }
 
 // Chains are numbered c = 2*e + axis: the puck's two chains come last (c >= 2*P).
 // Returns true when the arena must take the wave pass; discmask then holds the discs whose watch
 // fired (all discs when the division guard tripped).
-template <int N, bool FAST>
+template <int N, int MODE>
 __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__restrict__ ctl, long long a,
                                           unsigned &discmask) {
   constexpr int P = 2 * N, E = P + 1, PK = P, M = 2 * E;
@@ -131,12 +147,12 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
   bool wd[E];                                               // per-disc watch (lane masks live in SGPRs)
 #pragma unroll
   for (int e = 0; e < E; ++e) wd[e] = false;
-  if (FAST) {
+  if (MODE != DIV_IEEE) {
 #pragma unroll
     for (int c = 0; c < M; ++c) guard |= !fast_division_safe(u[c], vel[c]);
   }
   for (int i = 1; i <= kGrid; ++i) {
-    rk4_all_chains<FAST, M, 2 * PK>(pos, vel, u, p.tau_player, p.inv_tau_player, p.tau_puck, p.inv_tau_puck, dt_col);
+    rk4_all_chains<MODE, M, 2 * PK>(pos, vel, u, p.tau_player, p.inv_tau_player, p.tau_puck, p.inv_tau_puck, dt_col);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const double rad = e == PK ? kRPuck : kRPlayer;

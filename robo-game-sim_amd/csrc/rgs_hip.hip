@@ -65,8 +65,9 @@ struct HybridGroups {
   static constexpr int GPW = 64 / GW;
 };
 
-template <int N, bool FAST>
+template <int N, int MODE>
 __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
+  constexpr bool FAST = MODE != DIV_IEEE;
   extern __shared__ double lds[];
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   const int lane = threadIdx.x;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
   for (int k = 0; k < p.n_steps; ++k) {
     const double *ctl = p.ctl + (long long)k * p.ctl_stride;
     unsigned discmask = 0u;
-    const bool slow = mine && lane_step<N, FAST>(p, ctl, a, discmask);
+    const bool slow = mine && lane_step<N, MODE>(p, ctl, a, discmask);
     unsigned long long m = __ballot(slow);
     if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
     __syncthreads();                                 // lane-pass stores visible to the wave pass
@@ -180,6 +181,13 @@ bool fast_division_ok(double tau) {
   return frac < 0xFFFFFFFFFFFFFull - 64;
 }
 
+// +-2^k with a moderate exponent: 1/tau is exact and a*(1/tau) rounds exactly like a/tau.
+bool is_power_of_two(double tau) {
+  if (!fast_division_ok(tau)) return false;
+  int e;
+  return std::fabs(std::frexp(tau, &e)) == 0.5;
+}
+
 bool use_fast_division(const rgs_sim *s) {
   return s->fast_div && fast_division_ok(s->tau_player) && fast_division_ok(s->tau_puck);
 }
@@ -214,10 +222,12 @@ int launch_hybrid(rgs_sim *s, const StepArgs &args) {
   const long long blocks = (s->B + 63) / 64;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
   const bool fast = use_fast_division(s);
-  if (fast)
-    hipLaunchKernelGGL((k_step_hybrid<N, true>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  if (fast && is_power_of_two(s->tau_player))
+    hipLaunchKernelGGL((k_step_hybrid<N, DIV_PLAYER_POW2>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  else if (fast)
+    hipLaunchKernelGGL((k_step_hybrid<N, DIV_MARKSTEIN>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
   else
-    hipLaunchKernelGGL((k_step_hybrid<N, false>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+    hipLaunchKernelGGL((k_step_hybrid<N, DIV_IEEE>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_hybrid launch: ") + hipGetErrorString(e));
   return RGS_OK;
