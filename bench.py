@@ -55,7 +55,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-per-team", type=int, default=2)
     ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
-    ap.add_argument("--steps-per-launch", type=int, default=250)
+    ap.add_argument("--steps-per-launch", type=int, default=0,
+                    help="steps fused into one kernel launch (0 = all K: waves only re-synchronise at launch ends, so "
+                         "fewer launches = less tail)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 wave-per-arena, 2 hybrid")
     ap.add_argument("--cpu-sample-arenas", type=int, default=2048)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg (a 1-GPU box's CPU share)")
@@ -92,6 +94,8 @@ def main():
     from robo_game_py import workloads as w
 
     n, B, K, W = args.n_per_team, args.arenas, args.steps, args.warmup
+    if args.steps_per_launch <= 0:
+        args.steps_per_launch = max(K, 1)
     P = 2 * n
     S = rgp.state_size(n)
 
@@ -165,8 +169,20 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_arena_step(n) * B * (K / launches)
     launch_s = kernel_ms * 1e-3 / launches
     achieved = bytes_per_launch / launch_s / 1e9
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel (profiles/r01/hybrid_pmc.json:
+    # FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KB -> bytes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    # prescribes for gfx950), scaled to this launch's arena-steps.  Not collected live.
+    traffic = None
+    try:
+        if n == 2 and args.variant != 1:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "hybrid_pmc.json")))
+            per = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / (260 * 65536)
+            traffic = round(per * B * (K / launches) / 1e9, 4)
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/r01)",
+                "algorithmic_gb_per_launch": round(bytes_per_launch / 1e9, 4),
                 "kernel_ms_per_launch": round(launch_s * 1e3, 4), "launches": launches,
                 "bytes_per_arena_step": algorithmic_bytes_per_arena_step(n),
                 "note": "path is FP64-VALU/latency bound, not HBM bound; see fp64_model and DESIGN.md"}
