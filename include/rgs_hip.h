@@ -70,6 +70,15 @@ int rgs_step(rgs_sim *sim, const double *controls_host);
  * handle's stream; rgs_sync() or any rgs_get_* waits for it. */
 int rgs_step_device(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps);
 
+/* Stepping with the reference's log record captured after every step (src/GameSim.cpp:161-170,
+ * include/utils.h:64-76).  rec_dev: [n_steps][R][B] doubles on the device, R =
+ * rgs_record_size(n) = 3 + 2 + 2P + P*P + 1: t, TAS, TBS, puck xy, players' xy, the P damage blocks in
+ * the reference's byte order, and a final "executed" row (1.0 where the step really ran; the
+ * reference writes no record for a decided game).  One step + one record kernel per step. */
+int rgs_record_size(int n_per_team);
+int rgs_step_device_record(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps,
+                           double *rec_dev);
+
 int rgs_sync(rgs_sim *sim);
 
 /* The value GameSim::run / reset return (state_.vector(), src/GameSim.cpp:54,123), for all arenas. */

@@ -125,6 +125,36 @@ __global__ void k_reset(double *state, double *tcur, double *damage, const doubl
   (void)E;
 }
 
+// One log record per arena (src/GameSim.cpp:161-170, include/utils.h:64-76), SoA: rec[R][B] with
+// R = 3 + 2 + 2P + P*P + 1: t, TAS, TBS, puck xy, players' xy, the P "damage.row(k)" blocks exactly as
+// the reference writes them (P contiguous doubles starting at flat column-major element k), and a
+// last row "executed" (1.0 if this step advanced the arena: a decided game logs nothing, cpp:121).
+template <int N>
+__global__ void k_record(const double *state, const double *tcur, const double *damage, double *tprev,
+                         double *rec, long long B) {
+  constexpr int P = 2 * N;
+  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= B) return;
+  int r = 0;
+  const double t = tcur[a];
+  rec[(long long)(r++) * B + a] = t;
+  rec[(long long)(r++) * B + a] = state[0 * B + a];
+  rec[(long long)(r++) * B + a] = state[1 * B + a];
+  rec[(long long)(r++) * B + a] = state[2 * B + a];
+  rec[(long long)(r++) * B + a] = state[3 * B + a];
+  for (int e = 0; e < P; ++e) {
+    rec[(long long)(r++) * B + a] = state[(long long)(6 + 4 * e) * B + a];
+    rec[(long long)(r++) * B + a] = state[(long long)(7 + 4 * e) * B + a];
+  }
+  for (int k = 0; k < P; ++k)
+    for (int q = 0; q < P; ++q) {
+      const int flat = k + q;                         // column-major flat index: row = flat % P, col = flat / P
+      rec[(long long)(r++) * B + a] = damage[(long long)((flat % P) * P + flat / P) * B + a];
+    }
+  rec[(long long)(r++) * B + a] = (t != tprev[a]) ? 1.0 : 0.0;
+  tprev[a] = t;
+}
+
 __global__ void k_undecided(const double *state, long long B, double win, uint8_t *out) {
   const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= B) return;
@@ -158,7 +188,7 @@ struct rgs_sim {
   int variant = RGS_VARIANT_AUTO;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double *state = nullptr, *tcur = nullptr, *damage = nullptr, *ctl = nullptr;
+  double *state = nullptr, *tcur = nullptr, *damage = nullptr, *ctl = nullptr, *tprev = nullptr;
   unsigned long long *counters = nullptr;
   uint8_t *flags = nullptr;
   // reset() parameters, src/GameSim.cpp:27-46
@@ -333,6 +363,7 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   if (e == hipSuccess) e = hipMalloc(&s->state, sizeof(double) * s->S * s->B);
   if (e == hipSuccess) e = hipMalloc(&s->tcur, sizeof(double) * s->B);
   if (e == hipSuccess) e = hipMalloc(&s->damage, sizeof(double) * s->P * s->P * s->B);
+  if (e == hipSuccess) e = hipMalloc(&s->tprev, sizeof(double) * s->B);
   if (e == hipSuccess) e = hipMalloc(&s->ctl, sizeof(double) * s->P * 2 * s->B);
   if (e == hipSuccess) e = hipMalloc(&s->counters, sizeof(unsigned long long) * CNT_N);
   if (e == hipSuccess) e = hipMalloc(&s->flags, (size_t)s->B);
@@ -352,7 +383,7 @@ int rgs_destroy(rgs_sim *s) {
   if (!s) return RGS_OK;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  hipFree(s->state); hipFree(s->tcur); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
+  hipFree(s->state); hipFree(s->tcur); hipFree(s->tprev); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -389,6 +420,33 @@ int rgs_step_device(rgs_sim *s, const double *controls_dev, int64_t step_stride,
   if (n_steps == 0) return RGS_OK;
   HIP_TRY(hipSetDevice(s->device));
   return launch_steps(s, controls_dev, step_stride, n_steps);
+}
+
+int rgs_record_size(int n_per_team) { return 3 + 2 + 4 * n_per_team + 4 * n_per_team * n_per_team + 1; }
+
+int rgs_step_device_record(rgs_sim *s, const double *controls_dev, int64_t step_stride, int n_steps, double *rec_dev) {
+  if (!s || !controls_dev || !rec_dev || n_steps < 0 || step_stride < 0) return fail(RGS_ERR_ARG, "rgs_step_device_record: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const int R = rgs_record_size(s->n);
+  const int tb = 256;
+  const dim3 grid((unsigned)((s->B + tb - 1) / tb));
+  HIP_TRY(hipMemcpyAsync(s->tprev, s->tcur, sizeof(double) * s->B, hipMemcpyDeviceToDevice, s->stream));
+  for (int k = 0; k < n_steps; ++k) {
+    int rc = launch_steps(s, controls_dev + (long long)k * step_stride, 0, 1);
+    if (rc != RGS_OK) return rc;
+    double *rec = rec_dev + (long long)k * R * s->B;
+    switch (s->n) {
+      case 1: hipLaunchKernelGGL((k_record<1>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+      case 2: hipLaunchKernelGGL((k_record<2>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+      case 3: hipLaunchKernelGGL((k_record<3>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+      case 4: hipLaunchKernelGGL((k_record<4>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+      case 5: hipLaunchKernelGGL((k_record<5>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+      case 6: hipLaunchKernelGGL((k_record<6>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+      case 7: hipLaunchKernelGGL((k_record<7>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  return RGS_OK;
 }
 
 int rgs_sync(rgs_sim *s) {

@@ -212,6 +212,32 @@ class BatchedGameSim:
             buf.free()
         return self.state()
 
+    def record_size(self):
+        return int(self._L.rgs_record_size(self.n_per_team))
+
+    def run_table_recorded(self, table, chunk_steps=64):
+        """Step through a host control table (K, P, 2, B) and return the reference's log record of every
+        step for every arena: array (K, R, B), R = record_size(); row R-1 is 1.0 where the step executed."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        K = t.shape[0]
+        if t.shape[1:] != (self.players, 2, self.n_arenas):
+            raise TypeError("table must have shape (K, %d, 2, %d)" % (self.players, self.n_arenas))
+        R, B = self.record_size(), self.n_arenas
+        stride = self.players * 2 * B
+        out = np.empty((K, R, B))
+        ch = max(1, min(K, chunk_steps))
+        cbuf, rbuf = self.alloc(ch * stride), self.alloc(ch * R * B)
+        try:
+            for k0 in range(0, K, ch):
+                k1 = min(K, k0 + ch)
+                cbuf.upload(t[k0:k1])
+                _lib.check(self._L.rgs_step_device_record(self._h, C.c_void_p(cbuf.ptr), stride, k1 - k0, C.c_void_p(rbuf.ptr)))
+                out[k0:k1] = rbuf.download((k1 - k0) * R * B).reshape(k1 - k0, R, B)
+        finally:
+            cbuf.free()
+            rbuf.free()
+        return out
+
     def sync(self):
         _lib.check(self._L.rgs_sync(self._h))
 

@@ -1,0 +1,164 @@
+"""Monte-Carlo harness on the HIP stepper (reference: py/MonteCarlo.py:8-49).
+
+Two entry points:
+
+monte_carlo(mc_params, team_A_run_method, team_B_run_method, cbf_run_method=None)
+    Same signature, same call order and same files as the reference: one game after another, the
+    (stateful) team objects are called exactly as py/MonteCarlo.py:36-45 calls them, every step runs
+    on the GPU through the drop-in GameSim.  `py/mc_example_1.py`-style parameter bags work unchanged.
+
+monte_carlo_batched(mc_params, policy, ...)
+    All `num_runs` games advance together as one batch of arenas.  The policy must be vectorised
+    over runs (it receives the (S, B) state array); the reference's per-run seed (`seed=i`,
+    py/MonteCarlo.py:29) is available to it as `seeds`.  Writes the same configuration.txt and, for
+    the runs asked for, the same binary logs.
+
+Both write `configuration.txt` with the 13 scalars of py/MonteCarlo.py:14-21 and `mc_run_<i>.log`
+files of 29 native-endian doubles per executed step (matlab/interpret_mc_results.m:32-48 reads them).
+"""
+import math
+import os
+
+import numpy as np
+
+from . import BatchedGameSim, GameSim, log_record
+
+
+def write_configuration(mc_params):
+    """py/MonteCarlo.py:11-21: directory + configuration.txt, one `str(param)` per line."""
+    if not os.path.exists(mc_params.log_prefix):
+        os.makedirs(mc_params.log_prefix)
+    x0 = mc_params.x0_ball
+    values = [mc_params.num_runs, mc_params.T, mc_params.dt, mc_params.winning_score, x0[0], x0[1], x0[2], x0[3],
+              mc_params.noise_stdev, mc_params.tau_puck, mc_params.tau_player, mc_params.player_mass,
+              mc_params.puck_mass]
+    with open(os.path.join(mc_params.log_prefix, "configuration.txt"), "w") as f:
+        for v in values:
+            f.write(str(v) + "\n")
+
+
+def steps_per_run(mc_params):
+    """N = ceil(T/dt) controller steps (py/MonteCarlo.py:34) after the one zero-input step (:33)."""
+    return int(math.ceil(mc_params.T / mc_params.dt))
+
+
+class _StateView:
+    """Minimal py/src/SimState.py stand-in (index constants + state copy) for policies written for it."""
+    TAS, TBS, PK, A1, A2, B1, B2 = 0, 1, 2, 6, 10, 14, 18
+
+    def __init__(self, state):
+        self.state = np.array(state, dtype=np.float64, copy=True)
+
+    def get_player_state(self, team, player_id):
+        o = {("A", 1): 6, ("A", 2): 10, ("B", 1): 14, ("B", 2): 18}[(team, player_id)]
+        return self.state[o:o + 4]
+
+    def get_player_pos(self, team, player_id):
+        return self.get_player_state(team, player_id)[0:2].copy()
+
+    def get_player_vel(self, team, player_id):
+        return self.get_player_state(team, player_id)[2:4].copy()
+
+    def get_puck_state(self):
+        return self.state[2:6].copy()
+
+    def get_puck_pos(self):
+        return self.state[2:4].copy()
+
+    def get_puck_vel(self):
+        return self.state[4:6].copy()
+
+    def transpose(self):
+        return self.state.transpose().copy()
+
+
+def monte_carlo(mc_params, team_A_run_method, team_B_run_method, cbf_run_method=None, state_class=None,
+                sim=None, verbose=True):
+    """Drop-in for py/MonteCarlo.py:8-49 (sequential games, reference call order).
+
+    state_class: what the team methods receive (default: a SimState look-alike; pass the reference's
+    own `src.SimState.SimState` when running inside its tree).  Returns the list of final states.
+    """
+    state_class = state_class or _StateView
+    sim = sim or GameSim()
+    write_configuration(mc_params)
+    finals = []
+    for i in range(1, mc_params.num_runs + 1):
+        if verbose:
+            print("MC RUN # {} / {}:".format(i, mc_params.num_runs))
+        logname = os.path.join(mc_params.log_prefix, "mc_run_{}.log".format(i))
+        sim.reset(mc_params.dt, mc_params.winning_score, mc_params.x0_ball, mc_params.noise_stdev, True, logname, i,
+                  mc_params.tau_puck, mc_params.tau_player, mc_params.player_mass, mc_params.puck_mass)
+        sim_state = state_class(sim.run(np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2)))
+        for _ in range(steps_per_run(mc_params)):
+            velA1, velA2 = team_A_run_method(sim_state)
+            velB1, velB2 = team_B_run_method(sim_state)
+            if cbf_run_method is not None:
+                velA1, velA2, velB1, velB2 = cbf_run_method([velA1, velA2, velB1, velB2], sim_state)
+            sim_state = state_class(sim.run(velA1, velA2, velB1, velB2))
+        finals.append(np.array(sim_state.state, copy=True))
+    sim.reset(mc_params.dt, mc_params.winning_score, mc_params.x0_ball)     # closes the last log
+    if verbose:
+        print("DONE!")
+    return finals
+
+
+def mindless_policy(state, k, t, seeds):
+    """py/run_sim.py:62-65: every player is commanded (cos t, sin t)."""
+    P = (state.shape[0] - 6) // 4
+    u = np.empty((P, 2, state.shape[1]))
+    u[:, 0, :] = math.cos(t)
+    u[:, 1, :] = math.sin(t)
+    return u
+
+
+def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=0, write_logs=True, logged_runs=None,
+                        sim=None):
+    """All runs of the ensemble at once.
+
+    policy(state (S, B), k, t, seeds (B,)) -> controls (P, 2, B); called once per step for the whole batch
+    (k = step index, t = k*dt accumulated like py/run_sim.py:75).  logged_runs: iterable of 1-based run
+    numbers whose mc_run_<i>.log to write (default: all when write_logs).
+    Returns dict(state (S, B), scores (2, B), damage (P, P, B), undecided (B,), steps).
+    """
+    B = int(mc_params.num_runs)
+    if float(mc_params.noise_stdev) != 0.0:
+        raise ValueError("noise_stdev != 0 is not implemented on the device (SURVEY 8f-3)")
+    own = sim is None
+    sim = sim or BatchedGameSim(B, n_per_team, device)
+    P = sim.players
+    seeds = np.arange(1, B + 1)                                             # py/MonteCarlo.py:23,29
+    write_configuration(mc_params)
+    sim.reset(mc_params.dt, mc_params.winning_score, np.asarray(mc_params.x0_ball, dtype=np.float64), 0.0, False, "",
+              0, mc_params.tau_puck, mc_params.tau_player, mc_params.player_mass, mc_params.puck_mass)
+    N = steps_per_run(mc_params)
+    runs = list(range(1, B + 1)) if logged_runs is None else [int(r) for r in logged_runs]
+    files = {}
+    if write_logs:
+        for r in runs:
+            files[r] = open(os.path.join(mc_params.log_prefix, "mc_run_{}.log".format(r)), "wb")
+    R = sim.record_size()
+
+    def step(controls):
+        if files:
+            rec = sim.run_table_recorded(controls[None])[0]                 # (R, B)
+            for r, f in files.items():
+                if rec[R - 1, r - 1] != 0.0:                                # a decided game logs nothing
+                    f.write(rec[:R - 1, r - 1].tobytes())
+            return None
+        sim.step(controls)
+        return None
+
+    step(np.zeros((P, 2, B)))                                               # py/MonteCarlo.py:33
+    t = 0.0
+    for k in range(N):
+        state = sim.state()
+        step(np.ascontiguousarray(policy(state, k, t, seeds), dtype=np.float64))
+        t += mc_params.dt
+    for f in files.values():
+        f.close()
+    state = sim.state()
+    out = dict(state=state, scores=state[:2].copy(), damage=sim.damage(), undecided=sim.undecided(), steps=N + 1)
+    if own:
+        sim.close()
+    return out

@@ -1,0 +1,123 @@
+"""Callers either side of the hot path: Monte-Carlo harness and the binary log."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Params:                                            # py/mc_example_1.py:9-36, noise-free
+    def __init__(self, prefix, num_runs=3, T=4.0, dt=0.05):
+        self.log_prefix = prefix
+        self.num_runs = num_runs
+        self.noise_stdev = 0.0
+        self.T = T
+        self.dt = dt
+        self.tau_player = 0.5
+        self.tau_puck = 0.1
+        self.player_mass = 1.0
+        self.puck_mass = 0.5
+        self.winning_score = 2
+        self.x0_ball = np.array([-1.0, 0.0, 0.0, 0.0])
+
+
+def chase(team, sign):
+    """Stateless 'run method' in the shape of ClassicalTeam.run: SimState -> (vel1, vel2)."""
+    def run(sim_state):
+        pk = sim_state.get_puck_pos()
+        out = []
+        for pid in (1, 2):
+            d = pk - sim_state.get_player_pos(team, pid) + np.array([0.3 * sign, 0.05 * pid])
+            out.append(4.0 * d / max(1e-9, math.hypot(d[0], d[1])))
+        return out[0], out[1]
+    return run
+
+
+def oracle_game(oracle, params, logname, team_a, team_b, seed):
+    from robo_game_py.montecarlo import _StateView, steps_per_run
+    s = oracle.OracleGameSim()
+    s.reset(params.dt, params.winning_score, params.x0_ball, 0.0, True, logname, seed, params.tau_puck,
+            params.tau_player, params.player_mass, params.puck_mass)
+    st = _StateView(s.run(np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2)))
+    for _ in range(steps_per_run(params)):
+        a1, a2 = team_a(st)
+        b1, b2 = team_b(st)
+        st = _StateView(s.run(a1, a2, b1, b2))
+    s.reset(params.dt, params.winning_score, params.x0_ball)
+    return st.state
+
+
+def test_sequential_monte_carlo_writes_reference_files(rgp, oracle, tmp_path):
+    from robo_game_py.montecarlo import monte_carlo
+    p = Params(str(tmp_path / "gpu_mc"))
+    finals = monte_carlo(p, chase("A", -1), chase("B", 1), verbose=False)
+    cfg = open(os.path.join(p.log_prefix, "configuration.txt")).read().split("\n")
+    assert cfg[:4] == ["3", "4.0", "0.05", "2"] and cfg[4:8] == ["-1.0", "0.0", "0.0", "0.0"] and len(cfg) == 14
+    for i in range(1, p.num_runs + 1):
+        ref_log = str(tmp_path / ("oracle_%d.log" % i))
+        ref_final = oracle_game(oracle, p, ref_log, chase("A", -1), chase("B", 1), i)
+        got = open(os.path.join(p.log_prefix, "mc_run_%d.log" % i), "rb").read()
+        want = open(ref_log, "rb").read()
+        assert len(want) % (29 * 8) == 0 and len(want) > 29 * 8 * 10
+        assert got == want, "run %d: log bytes differ" % i
+        assert np.array_equal(finals[i - 1], ref_final)
+
+
+def test_batched_monte_carlo_equals_sequential(rgp, oracle, tmp_path):
+    from robo_game_py.montecarlo import monte_carlo_batched
+    p = Params(str(tmp_path / "gpu_mc_batched"), num_runs=48)
+    p.winning_score = 1                                  # so that some games end before T
+
+    def policy(state, k, t, seeds):                      # vectorised chase with a per-run (seeded) offset
+        P, B = 4, state.shape[1]
+        u = np.empty((P, 2, B))
+        for e in range(P):
+            d = state[2:4] - state[6 + 4 * e:8 + 4 * e]
+            d = d + np.stack([0.01 * seeds * (1 if e < 2 else -1), 0.02 * (e + 1) * np.ones(B)])
+            u[e] = 4.0 * d / np.maximum(1e-9, np.sqrt(d[0] * d[0] + d[1] * d[1]))
+        return u
+
+    out = monte_carlo_batched(p, policy, logged_runs=[1, 7, 48])
+    assert out["steps"] == 81 and out["state"].shape == (22, 48)
+    assert sorted(f for f in os.listdir(p.log_prefix)) == ["configuration.txt", "mc_run_1.log", "mc_run_48.log", "mc_run_7.log"]
+    # the same games, one at a time, on the oracle with the same policy restricted to one run
+    for r in (1, 7, 48):
+        s = oracle.OracleGameSim()
+        ref_log = str(tmp_path / ("o_%d.log" % r))
+        s.reset(p.dt, p.winning_score, p.x0_ball, 0.0, True, ref_log, r, p.tau_puck, p.tau_player, p.player_mass, p.puck_mass)
+        st = s.run(np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2))
+        for k in range(80):
+            u = policy(st.reshape(22, 1), k, 0.0, np.array([r]))
+            st = s.run(np.ascontiguousarray(u[:, :, 0]))
+        s.reset(p.dt, p.winning_score, p.x0_ball)
+        assert np.array_equal(out["state"][:, r - 1], st)
+        assert open(os.path.join(p.log_prefix, "mc_run_%d.log" % r), "rb").read() == open(ref_log, "rb").read()
+    assert out["scores"].sum() > 0 and (~out["undecided"]).any()       # some games were decided early
+
+
+def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path):
+    """run_table_recorded returns exactly the reference's per-step record for every arena (4v4 too)."""
+    from robo_game_py import workloads as w
+    for n in (2, 4):
+        B, K = 6, 60
+        x0, _, _ = w.c2_inputs(B, n, seed=8)
+        table = w.random_hold_controls(2 * n, B, K, 10.0, hold=10, seed=n)
+        sim = rgp.BatchedGameSim(B, n)
+        sim.reset(0.05, 1, x0)
+        rec = sim.run_table_recorded(table)
+        R = sim.record_size()
+        assert rec.shape == (K, R, B) and R == 3 + 2 + 4 * n + 4 * n * n + 1
+        for a in range(B):
+            path = str(tmp_path / ("n%d_a%d.log" % (n, a)))
+            o = oracle.OracleGameSim(n)
+            o.reset(0.05, 1, x0[:, a], 0.0, True, path)
+            for k in range(K):
+                o.run(np.ascontiguousarray(table[k, :, :, a]))
+            o.reset(0.05, 1, x0[:, a])
+            want = np.frombuffer(open(path, "rb").read(), dtype=np.float64).reshape(-1, R - 1)
+            ran = rec[:, R - 1, a] != 0.0
+            assert ran.sum() == len(want)
+            assert np.array_equal(rec[ran, :R - 1, a], want)
+        sim.close()
