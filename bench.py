@@ -31,7 +31,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "robo-game-sim_amd"))
 
 ARENAS_PER_GPU = 65536
-DT = 0.01
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes/2 (fp64 half rate) x 2 flop x 2.4 GHz
 
@@ -51,10 +50,14 @@ def model_flops_per_arena_step(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps K (default 1000; 201 for c4 = 1 + ceil(T/dt))")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n-per-team", type=int, default=2)
-    ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json workload: c2 = 65 536 x 2v2 (the headline metric, default); c3 = 65 536 x 7v7; "
+                         "c4 = Monte-Carlo 2v2, mc_example_1.py parameters, 131 072 arenas per GPU; c5 = 4v4 with "
+                         "per-step host-streamed controls, 32 768 arenas per GPU (also reports the PCIe-inclusive rate)")
+    ap.add_argument("--n-per-team", type=int, default=None)
+    ap.add_argument("--arenas", type=int, default=None, help="arenas per GPU")
     ap.add_argument("--steps-per-launch", type=int, default=0,
                     help="steps fused into one kernel launch (0 = all K: waves only re-synchronise at launch ends, so "
                          "fewer launches = less tail)")
@@ -67,6 +70,15 @@ def main():
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
     args = ap.parse_args()
+    preset = {"c2": (2, 65536, 0.01, 1000000), "c3": (7, 65536, 0.01, 1000000), "c4": (2, 131072, 0.05, 4),
+              "c5": (4, 32768, 0.05, 1000000)}[args.config]
+    if args.n_per_team is None:
+        args.n_per_team = preset[0]
+    if args.arenas is None:
+        args.arenas = preset[1]
+    DT, WIN = preset[2], preset[3]
+    if args.steps is None:
+        args.steps = 201 if args.config == "c4" else 1000
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,7 +134,9 @@ def main():
 
     sim = rgp.BatchedGameSim(B, n, device=local_rank)
     sim.set_variant(args.variant)
-    sim.reset(DT, 1000000, np.ascontiguousarray(x0))
+    if args.config == "c4":                                    # mc_example_1.py:13-30: every run starts from x0_ball
+        x0 = np.repeat(np.array([[-1.0], [0.0], [0.0], [0.0]]), B, axis=1)
+    sim.reset(DT, WIN, np.ascontiguousarray(x0))
     from robo_game_py.ensemble import all_gather_states
     mine = torch.empty((S, B), dtype=torch.float64, device=dev)
 
@@ -164,6 +178,31 @@ def main():
     total_arena_steps = float(B) * world * K
     value = total_arena_steps / elapsed
     counters = sim.counters()
+    sample_state = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sample_state = sim.state()[:, :min(args.cpu_sample_arenas, B)].copy()      # before anything else steps the arenas
+
+    # ---- C5: the same steps driven from the host, one control upload + one state download per step ----
+    streamed = None
+    if args.config == "c5":
+        ks = min(K, 200)
+        host_table = table[W:W + ks].cpu().numpy()               # stands in for the controller's output
+        ctl_pin, st_pin = sim.pinned((P, 2, B)), sim.pinned((S, B))
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(ks):
+            ctl_pin[...] = host_table[k]
+            sim.step_roundtrip(ctl_pin, st_pin)
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        streamed = {"value": round(float(B) * world * ks / el, 1), "unit": "arena-steps/s", "steps": ks,
+                    "ms_per_step": round(el * 1e3 / ks, 4),
+                    "bytes_per_step_per_gpu": {"h2d_controls": P * 2 * B * 8, "d2h_state": S * B * 8},
+                    "note": "PCIe-inclusive closed-loop rate (pinned buffers, host memcpy of the controls included); "
+                            "never the headline value"}
 
     # ---- roofline of the stepping kernel (per launch) ------------------------------------------
     bytes_per_launch = algorithmic_bytes_per_arena_step(n) * B * (K / launches)
@@ -174,7 +213,7 @@ def main():
     # prescribes for gfx950), scaled to this launch's arena-steps.  Not collected live.
     traffic = None
     try:
-        if n == 2 and args.variant != 1:
+        if n == 2 and args.variant != 1 and args.config == "c2":
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "hybrid_pmc.json")))
             per = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / (260 * 65536)
             traffic = round(per * B * (K / launches) / 1e9, 4)
@@ -200,14 +239,14 @@ def main():
         sub = table[:, :, :, :cs].contiguous().cpu().numpy()     # the very values the GPU consumed
         x0s = np.ascontiguousarray(x0[:, :cs])
         t1 = time.perf_counter()
-        ref = orc.batch_run(n, x0s, sub, W + K, dt=DT, winning_score=1000000, n_threads=cores)
+        ref = orc.batch_run(n, x0s, sub, W + K, dt=DT, winning_score=WIN, n_threads=cores)
         cpu_s = time.perf_counter() - t1
         cf = max(1, cs // 4)
         t1 = time.perf_counter()
         orc.batch_run(n, np.ascontiguousarray(x0s[:, :cf]), np.ascontiguousarray(sub[:, :, :, :cf]), W + K, dt=DT,
-                      winning_score=1000000, n_threads=cores, draw_always=True)
+                      winning_score=WIN, n_threads=cores, draw_always=True)
         cpu_faithful_s = time.perf_counter() - t1
-        got = sim.state()[:, :cs]
+        got = sample_state
         delta = float(np.max(np.abs(got - ref["state"])))
         parity = {"arenas_checked": cs, "steps": W + K, "max_abs_delta_vs_oracle": delta,
                   "scores_equal": bool(np.array_equal(got[:2], ref["state"][:2])),
@@ -225,10 +264,11 @@ def main():
             "value": round(value, 1), "unit": "arena-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed * 1e3 / K, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: %d parallel %dv%d arenas per GPU, dt=0.01, circle controls, rng 20260" % (B, n, n),
+            "config": {"workload": "%s: %d parallel %dv%d arenas per GPU, dt=%g, winning_score=%d, circle controls, rng 20260"
+                                   % (args.config.upper(), B, n, n, DT, WIN),
                        "arenas_per_gpu": B, "n_per_team": n, "steps_per_launch": args.steps_per_launch,
                        "variant": args.variant, "parallelism": "arena-sharded x%d, end-of-run all-gather" % world},
-            "roofline": roofline, "fp64_model": fp64_model, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "fp64_model": fp64_model, "cpu_baseline": cpu, "parity": parity, "host_streamed": streamed,
             "events": counters,
         }
         print(json.dumps(out), flush=True)

@@ -103,6 +103,13 @@ int rgs_device_free(rgs_sim *sim, double *dev);
 int rgs_device_upload(rgs_sim *sim, double *dst_dev, const double *src_host, int64_t n_doubles);
 int rgs_device_download(rgs_sim *sim, double *dst_host, const double *src_dev, int64_t n_doubles);
 
+/* Closed-loop use by a host-side controller (py/test_dmpc.py:43-47, py/run_sim.py:56-75): upload this
+ * step's controls [P][2][B], advance one step, download the state [S][B]; one synchronisation.
+ * rgs_host_alloc gives page-locked buffers so both copies run at PCIe rate. */
+int rgs_step_roundtrip(rgs_sim *sim, const double *controls_host, double *state_host);
+int rgs_host_alloc(int64_t n_doubles, double **out_host);
+int rgs_host_free(double *host);
+
 /* HIP-event timer on the handle's stream: start ... launches ... stop -> milliseconds. */
 int rgs_timer_start(rgs_sim *sim);
 int rgs_timer_stop(rgs_sim *sim, float *ms_out);

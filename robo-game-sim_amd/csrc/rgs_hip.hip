@@ -552,6 +552,32 @@ int rgs_device_download(rgs_sim *s, double *dst, const double *src, int64_t n) {
   return RGS_OK;
 }
 
+// Pinned host memory: lets rgs_step_pinned overlap nothing but at least run the PCIe copies at
+// full rate (pageable numpy buffers are staged by the runtime).
+int rgs_host_alloc(int64_t n_doubles, double **out_host) {
+  if (!out_host || n_doubles < 1) return fail(RGS_ERR_ARG, "rgs_host_alloc: bad argument");
+  HIP_TRY(hipHostMalloc((void **)out_host, sizeof(double) * (size_t)n_doubles, hipHostMallocDefault));
+  return RGS_OK;
+}
+
+int rgs_host_free(double *host) {
+  HIP_TRY(hipHostFree(host));
+  return RGS_OK;
+}
+
+// One closed-loop step for a host-side controller (py/test_dmpc.py:43-47 shape): controls H2D,
+// one step, state D2H, all asynchronous on the handle's stream, one synchronisation at the end.
+int rgs_step_roundtrip(rgs_sim *s, const double *controls_host, double *state_host) {
+  if (!s || !controls_host || !state_host) return fail(RGS_ERR_ARG, "rgs_step_roundtrip: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(s->ctl, controls_host, sizeof(double) * s->P * 2 * s->B, hipMemcpyHostToDevice, s->stream));
+  int rc = launch_steps(s, s->ctl, 0, 1);
+  if (rc != RGS_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(state_host, s->state, sizeof(double) * s->S * s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
 int rgs_timer_start(rgs_sim *s) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_timer_start: null handle");
   HIP_TRY(hipSetDevice(s->device));

@@ -144,11 +144,15 @@ class BatchedGameSim:
         self.state_size = state_size(self.n_per_team)
         self.device = int(device)
         self.params = reset_arguments()
+        self._pinned = []
 
     def close(self):
         if getattr(self, "_h", None):
             self._L.rgs_destroy(self._h)
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                self._L.rgs_host_free(C.c_void_p(p))
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -237,6 +241,22 @@ class BatchedGameSim:
             cbuf.free()
             rbuf.free()
         return out
+
+    def pinned(self, shape):
+        """A float64 numpy array over page-locked host memory (freed with the sim)."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        _lib.check(self._L.rgs_host_alloc(n, C.byref(p)))
+        self._pinned.append(p.value)
+        buf = (C.c_double * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.float64).reshape(shape)
+
+    def step_roundtrip(self, controls, state_out):
+        """controls (P, 2, B) -> one step -> state_out (S, B); both should come from pinned()."""
+        assert controls.shape == (self.players, 2, self.n_arenas) and controls.flags["C_CONTIGUOUS"]
+        assert state_out.shape == (self.state_size, self.n_arenas) and state_out.flags["C_CONTIGUOUS"]
+        _lib.check(self._L.rgs_step_roundtrip(self._h, _lib.dptr(controls), _lib.dptr(state_out)))
+        return state_out
 
     def sync(self):
         _lib.check(self._L.rgs_sync(self._h))

@@ -47,6 +47,9 @@ SIGNATURES = {
     "rgs_device_free": (C.c_int, [_vp, _vp]),
     "rgs_device_upload": (C.c_int, [_vp, _vp, _dp, C.c_int64]),
     "rgs_device_download": (C.c_int, [_vp, _dp, _vp, C.c_int64]),
+    "rgs_step_roundtrip": (C.c_int, [_vp, _dp, _dp]),
+    "rgs_host_alloc": (C.c_int, [C.c_int64, C.POINTER(_vp)]),
+    "rgs_host_free": (C.c_int, [_vp]),
     "rgs_timer_start": (C.c_int, [_vp]),
     "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
