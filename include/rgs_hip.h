@@ -39,7 +39,8 @@ enum {
 enum {
   RGS_VARIANT_AUTO = 0,
   RGS_VARIANT_WAVE = 1,      /* one wavefront owns one arena, grid in LDS */
-  RGS_VARIANT_HYBRID = 2     /* lane-per-arena streaming pass + LDS event pass */
+  RGS_VARIANT_HYBRID = 2,    /* lane-per-arena streaming pass + LDS event pass */
+  RGS_VARIANT_HYBRID2 = 3    /* the same with two lanes (x chains, y chains) per arena */
 };
 
 /* Human-readable text for the most recent failure on this thread. */

@@ -191,4 +191,76 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
   return false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two lanes per arena: the even lane carries every disc's x chain, the odd lane the y chains.
+//
+// The chains of the two axes never interact inside an event-free step; only the overlap watch
+// needs both (dx^2 + dy^2), which one DPP quad exchange per pair provides.  Same arithmetic per
+// chain as lane_step, so the same bits.  What it buys: half the registers per lane and twice the
+// waves (65 536 arenas = 2048 waves = two per SIMD), so while one wave sits in its latency-bound
+// wave pass the SIMD's other wave keeps the FP64 pipe busy.
+__device__ __forceinline__ unsigned quad_xor1_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);
+}
+
+template <int N, int MODE>
+__device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double *__restrict__ ctl, long long a, int ax,
+                                                unsigned &discmask) {
+  constexpr int P = 2 * N, E = P + 1, PK = P;
+  const long long B = p.B;
+  const double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
+  if (!(TAS < p.win && TBS < p.win)) return false;          // decided (both lanes of the arena agree)
+
+  double pos[E], vel[E], u[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int row = state_row<N>(e);
+    pos[e] = p.state[(long long)(row + ax) * B + a];
+    vel[e] = p.state[(long long)(row + 2 + ax) * B + a];
+    u[e] = e != PK ? ctl[(long long)(2 * e + ax) * B + a] : 0.0;   // cpp:188
+  }
+  const double dt_col = p.dt_col;
+  bool guard = false;
+  bool wd[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) wd[e] = false;
+  if (MODE != DIV_IEEE) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) guard |= !fast_division_safe(u[e], vel[e]);
+  }
+  const double half_extent = ax == 0 ? kX / 2.0 : kY / 2.0;
+  const double thr_pl = half_extent - kRPlayer - kWatchSlack, thr_pk = half_extent - kRPuck - kWatchSlack;
+  for (int i = 1; i <= kGrid; ++i) {
+    rk4_all_chains<MODE, E, PK>(pos, vel, u, p.tau_player, p.inv_tau_player, p.tau_puck, p.inv_tau_puck, dt_col);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      wd[e] |= !(__builtin_fabs(pos[e]) < (e == PK ? thr_pk : thr_pl));     // NaN counts as overlap
+#pragma unroll
+      for (int o = e + 1; o < E; ++o) {
+        const double rsum = (e == PK ? kRPuck : kRPlayer) + (o == PK ? kRPuck : kRPlayer);
+        const double r2 = rsum * rsum * (1.0 + kWatchSlack);
+        const double d = pos[e] - pos[o];
+        const double sq = d * d;
+        const bool near = !(sq + quad_xor1(sq) > r2);       // both lanes of the arena compute the same sum
+        wd[e] |= near;
+        wd[o] |= near;
+      }
+    }
+  }
+  discmask = guard ? ~0u : 0u;
+#pragma unroll
+  for (int e = 0; e < E; ++e) discmask |= wd[e] ? (1u << e) : 0u;
+  discmask |= quad_xor1_u32(discmask);                      // a wall flag seen by either axis
+  if (discmask != 0u) return true;
+
+#pragma unroll
+  for (int e = 0; e < E; ++e) {                             // cpp:153-157, this lane's axis
+    const int row = state_row<N>(e);
+    p.state[(long long)(row + ax) * B + a] = pos[e];
+    p.state[(long long)(row + 2 + ax) * B + a] = vel[e];
+  }
+  if (ax == 0) p.tcur[a] = p.tcur[a] + p.dt;                // cpp:158
+  return false;
+}
+
 }  // namespace gsim

@@ -100,6 +100,43 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
   }
 }
 
+// Hybrid with two lanes per arena (gsim_lane.hpp, lane_step_split): 32 arenas per wave.
+template <int N, int MODE>
+__global__ __launch_bounds__(64) void k_step_hybrid2(StepArgs p) {
+  constexpr bool FAST = MODE != DIV_IEEE;
+  extern __shared__ double lds[];
+  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
+  const int lane = threadIdx.x;
+  const int grp = lane / GW, lg = lane % GW;
+  const long long a0 = (long long)blockIdx.x * 32;
+  const long long a = a0 + (lane >> 1);
+  const int ax = lane & 1;
+  const bool mine = a < p.B;
+  double *G = lds + grp * WaveLayout<N>::DOUBLES;
+  for (int k = 0; k < p.n_steps; ++k) {
+    const double *ctl = p.ctl + (long long)k * p.ctl_stride;
+    unsigned discmask = 0u;
+    const bool slow = mine && lane_step_split<N, MODE>(p, ctl, a, ax, discmask);
+    unsigned long long m = __ballot(slow) & 0x5555555555555555ull;      // one bit per arena (its x lane)
+    if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
+    __syncthreads();
+    while (m != 0ull) {
+      int bit = -1;
+      unsigned long long mm = m;
+#pragma unroll
+      for (int i = 0; i < GPW; ++i) {
+        const int b = mm != 0ull ? __builtin_ctzll(mm) : -1;
+        if (i == grp) bit = b;
+        mm &= mm - 1ull;
+      }
+      m = mm;
+      const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
+      if (bit >= 0) arena_step_group<N, GW, FAST>(p, ctl, a0 + (bit >> 1), G, lg, lane - lg, dm);
+    }
+    __syncthreads();
+  }
+}
+
 // GameSim::reset on the device (src/GameSim.cpp:27-39); players spawn in rows (n = 2: +-Y/4).
 template <int N>
 __global__ void k_reset(double *state, double *tcur, double *damage, const double *x0, int x0_batched,
@@ -263,6 +300,22 @@ int launch_hybrid(rgs_sim *s, const StepArgs &args) {
   return RGS_OK;
 }
 
+template <int N>
+int launch_hybrid2(rgs_sim *s, const StepArgs &args) {
+  const long long blocks = (s->B + 31) / 32;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
+  const bool fast = use_fast_division(s);
+  if (fast && is_power_of_two(s->tau_player))
+    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_PLAYER_POW2>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  else if (fast)
+    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_MARKSTEIN>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  else
+    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_IEEE>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_hybrid2 launch: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
 int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps) {
   StepArgs a;
   a.dt = s->dt; a.dt_col = s->dt_col;
@@ -277,7 +330,21 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.ctl = ctl_dev; a.ctl_stride = stride; a.n_steps = n_steps;
   a.counters = s->counters;
   a.queue = nullptr; a.queue_count = nullptr;
-  if (s->variant != RGS_VARIANT_WAVE) {
+  // AUTO: measured on MI355X (profiles/r01): one lane per arena wins up to 3v3; from 4v4 on its
+  // register footprint spills and the two-lanes-per-arena form is faster (4v4 +48 %, 7v7 +11 %).
+  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->n >= 4 ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID);
+  if (variant == RGS_VARIANT_HYBRID2) {
+    switch (s->n) {
+      case 1: return launch_hybrid2<1>(s, a);
+      case 2: return launch_hybrid2<2>(s, a);
+      case 3: return launch_hybrid2<3>(s, a);
+      case 4: return launch_hybrid2<4>(s, a);
+      case 5: return launch_hybrid2<5>(s, a);
+      case 6: return launch_hybrid2<6>(s, a);
+      case 7: return launch_hybrid2<7>(s, a);
+    }
+  }
+  if (variant != RGS_VARIANT_WAVE) {
     switch (s->n) {
       case 1: return launch_hybrid<1>(s, a);
       case 2: return launch_hybrid<2>(s, a);
@@ -603,7 +670,7 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
 }
 
 int rgs_set_variant(rgs_sim *s, int variant) {
-  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_HYBRID) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
+  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_HYBRID2) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
   return RGS_OK;
 }

@@ -17,7 +17,7 @@ RGS_ERR_HIP = -2
 RGS_ERR_UNSUPPORTED = -3
 RGS_ERR_NO_DEVICE = -4
 
-VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID = 0, 1, 2
+VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2 = 0, 1, 2, 3
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p

@@ -191,7 +191,7 @@ def test_reference_sample_values_through_dropin(rgp):
     assert np.array_equal(st1, st2)
 
 
-VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid")]
+VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid"), pytest.param(3, id="hybrid2")]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
