@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a single GPU)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
+    ap.add_argument("--watch-every", type=int, default=-1, help="diagnostic: pair-watch interval (0 dense, 2, 5, 10)")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
     args = ap.parse_args()
     preset = {"c2": (2, 65536, 0.01, 1000000), "c3": (7, 65536, 0.01, 1000000), "c4": (2, 131072, 0.05, 4),
@@ -134,6 +135,8 @@ def main():
 
     sim = rgp.BatchedGameSim(B, n, device=local_rank)
     sim.set_variant(args.variant)
+    if args.watch_every >= 0:
+        sim.set_sparse_watch(args.watch_every)
     if args.config == "c4":                                    # mc_example_1.py:13-30: every run starts from x0_ball
         x0 = np.repeat(np.array([[-1.0], [0.0], [0.0], [0.0]]), B, axis=1)
     sim.reset(DT, WIN, np.ascontiguousarray(x0))

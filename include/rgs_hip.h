@@ -130,6 +130,11 @@ int rgs_set_variant(rgs_sim *sim, int variant);
  * select it automatically. */
 int rgs_set_fast_division(rgs_sim *sim, int enable);
 
+/* The lane pass evaluates the disc-pair part of its (conservative) overlap watch every 5th sub-step
+ * against radii widened by the largest possible travel in between; enable = 0 evaluates it at every
+ * sub-step (slower, same results).  Batches with dt_col/tau > 0.1 use every sub-step automatically. */
+int rgs_set_sparse_watch(rgs_sim *sim, int enable);
+
 /* fast[i] = a[i]/tau by the reciprocal sequence, ieee[i] = a[i]/tau by IEEE '/', both on the GPU. */
 int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double tau, double *fast_host,
                         double *ieee_host);

@@ -49,6 +49,7 @@ struct StepArgs {
   const double *ctl;                 // [P][2][B] of step 0
   long long ctl_stride;              // doubles between consecutive steps' controls
   int n_steps;
+  int watch_every;                   // lane pass: overlap watch every 5th column (1 = every column)
   unsigned long long *counters;      // [CNT_N]
   int *queue;                        // hybrid: [B] arena indices needing the event pass
   int *queue_count;                  // hybrid: [n_steps] or [1]

@@ -232,6 +232,8 @@ struct rgs_sim {
   double dt = 0.05, dt_col = 0.05 / kGrid, tau_puck = 0.1, tau_player = 0.5, m_player = 1.0, m_puck = 0.5;
   int win = 3, seed = 0;
   bool fast_div = true;            // cleared by rgs_set_fast_division(0) or by unsuitable taus
+  bool sparse_watch = true;        // cleared by rgs_set_sparse_watch(0)
+  int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
 };
 
 namespace {
@@ -328,6 +330,20 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.B = s->B;
   a.state = s->state; a.tcur = s->tcur; a.damage = s->damage;
   a.ctl = ctl_dev; a.ctl_stride = stride; a.n_steps = n_steps;
+  {  // the sparse watch's travel bound needs the velocities to stay inside [v0, u]: small dt_col/tau
+    const double zp = s->dt_col / s->tau_player, zk = 0.2 * s->dt_col / s->tau_puck;
+    const bool ok = s->sparse_watch && zp > 0.0 && zp <= 0.1 && zk > 0.0 && zk <= 0.1;
+    // Interval: the pair radius is widened by ~3.5*(we-1)*dt_col*vb, and every arena inside the widened
+    // radius costs a wave pass.  Measured (profiles/r01): dt = 0.01 is fastest at 5, dt = 0.05 at 2, i.e.
+    // the largest of {5, 2, 1} whose skipped time (we-1)*dt_col stays within 1 ms; rgs_set_sparse_watch
+    // can pin it.
+    int we = 1;
+    if (ok) {
+      if (s->watch_every > 0) we = s->watch_every;
+      else we = 4.0 * s->dt_col <= 1.0e-3 ? 5 : (s->dt_col <= 1.0e-3 ? 2 : 1);
+    }
+    a.watch_every = we;
+  }
   a.counters = s->counters;
   a.queue = nullptr; a.queue_count = nullptr;
   // AUTO: measured on MI355X (profiles/r01): one lane per arena wins up to 3v3; from 4v4 on its
@@ -678,6 +694,15 @@ int rgs_set_variant(rgs_sim *s, int variant) {
 int rgs_set_fast_division(rgs_sim *s, int enable) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_set_fast_division: null handle");
   s->fast_div = enable != 0;
+  return RGS_OK;
+}
+
+int rgs_set_sparse_watch(rgs_sim *s, int enable) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_set_sparse_watch: null handle");
+  if (enable != 0 && enable != 1 && enable != 2 && enable != 5 && enable != 10)
+    return fail(RGS_ERR_ARG, "rgs_set_sparse_watch: interval must be 0 (off), 1 (default interval), 2, 5 or 10");
+  s->sparse_watch = enable != 0;
+  if (enable >= 2) s->watch_every = enable;
   return RGS_OK;
 }
 

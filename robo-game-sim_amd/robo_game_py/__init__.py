@@ -296,6 +296,9 @@ class BatchedGameSim:
     def set_fast_division(self, enable):
         _lib.check(self._L.rgs_set_fast_division(self._h, int(bool(enable))))
 
+    def set_sparse_watch(self, enable):
+        _lib.check(self._L.rgs_set_sparse_watch(self._h, int(enable)))
+
     def alloc(self, n_doubles):
         return _DeviceBuffer(self, n_doubles)
 

@@ -139,6 +139,32 @@ def test_fast_and_ieee_division_builds_agree(rgp, oracle):
     assert_same(res[0], ref["state"], "fast division vs oracle")
 
 
+@pytest.mark.parametrize("variant", [2, 3], ids=["hybrid", "hybrid2"])
+@pytest.mark.parametrize("n,dt,tau_player", [(2, 0.01, 0.5), (2, 0.05, 0.5), (4, 0.05, 0.5), (2, 0.05, 0.005)])
+def test_sparse_watch_equals_dense_watch(rgp, oracle, n, dt, tau_player, variant):
+    """The lane pass' overlap watch runs every 5th sub-step with widened thresholds; evaluating it at
+    every sub-step instead must give the same bits (tau_player = 0.005 forces the dense watch: dt_col/tau
+    > 0.1), and fast players (|u| up to 10) must never slip through between checks."""
+    from robo_game_py import workloads as w
+    B, K = 512, 200
+    x0, _, _ = w.c2_inputs(B, n, seed=41)
+    table = w.random_hold_controls(2 * n, B, K, 10.0, hold=15, seed=13)
+    res, cnt = [], []
+    for sparse in (True, False):
+        sim = rgp.BatchedGameSim(B, n)
+        sim.set_variant(variant)
+        sim.set_sparse_watch(sparse)
+        sim.reset(dt, 1000, x0, 0.0, False, "", 0, 0.1, tau_player)
+        res.append(sim.run_table(table))
+        cnt.append(sim.counters())
+        sim.close()
+    assert_same(res[0], res[1], "sparse vs dense watch")
+    assert cnt[0]["resolved"] == cnt[1]["resolved"] and cnt[0]["flagged"] >= cnt[1]["flagged"]
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, tau_player=tau_player)
+    assert_same(res[0], ref["state"], "sparse watch vs oracle")
+    assert cnt[0]["resolved"] == ref["stats"]["resolved"] and ref["stats"]["resolved"] > 500
+
+
 def test_tiny_velocities_take_the_exact_path(rgp, oracle):
     """Puck speeds decaying through 1e-200 .. denormal: outside div_tau<true>'s window, so the lane
     pass must hand those arenas to the IEEE wave pass; results stay bit-identical."""
