@@ -69,6 +69,7 @@ def main():
                     "rehearse the multi-rank path on a single GPU)")
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--watch-every", type=int, default=-1, help="diagnostic: pair-watch interval (0 dense, 2, 5, 10)")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic: in-kernel phase stamps (slightly perturbs timing)")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
     args = ap.parse_args()
     preset = {"c2": (2, 65536, 0.01, 1000000), "c3": (7, 65536, 0.01, 1000000), "c4": (2, 131072, 0.05, 4),
@@ -159,6 +160,8 @@ def main():
         torch.cuda.synchronize()
         sim.sync()
 
+    if args.stamps:
+        sim.stamps(True)
     # ---- warm-up, then the timed region ----------------------------------------------------
     run_steps(0, W)
     barrier()
@@ -181,6 +184,8 @@ def main():
     total_arena_steps = float(B) * world * K
     value = total_arena_steps / elapsed
     counters = sim.counters()
+    if args.stamps:
+        counters["stamps"] = sim.stamps(True)
     sample_state = None
     if rank == 0 and world == 1 and not args.no_cpu:
         sample_state = sim.state()[:, :min(args.cpu_sample_arenas, B)].copy()      # before anything else steps the arenas

@@ -122,6 +122,13 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * event, [5] arena-steps the hybrid's lane pass handed to the wave pass, [6..7] reserved. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
+/* Diagnostic in-kernel stamps (s_memtime) of the one-lane hybrid kernel; only in a library built with
+ * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable
+ * applies to later launches; out9 (may be NULL) receives 9 totals since the last reset, summed over
+ * waves: lane-pass cycles, wave-pass cycles, wave-pass rounds, whole-kernel cycles, then for lane
+ * group 0 of every wave pass: fill, first-scan, event-loop, commit cycles and the arena count. */
+int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out9);
+
 int rgs_set_variant(rgs_sim *sim, int variant);
 
 /* The lane pass divides by tau_player / tau_puck with a reciprocal-plus-two-corrections sequence

@@ -10,6 +10,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostic in-kernel phase stamps (s_memtime).  Compiled out by default: even as never-taken
+// run-time branches they cost the one-lane hybrid kernel 2.7 % (measured).  `make STAMPS=1` builds
+// the diagnostic library; rgs_get_stamps() then returns the phase totals.
+#ifndef GSIM_STAMPS
+#define GSIM_STAMPS 0
+#endif
+
 namespace gsim {
 
 constexpr int kGrid = 50;          // sub-steps per step        include/GameSim.h:6
@@ -28,7 +35,10 @@ enum Counter : int {
   CNT_SKIPPED = 3,        // puck events dropped after a goal, cpp:230-231
   CNT_EVENT_STEPS = 4,    // arena-steps whose first scan found an event
   CNT_FLAGGED = 5,        // hybrid: arena-steps the lane pass handed to the wave pass
-  CNT_N = 8
+  CNT_N = 8,
+  // diagnostic stamps (StepArgs::stamps != 0): summed over waves, shader cycles
+  STAMP_LANE = 0, STAMP_WAVE = 1, STAMP_ROUNDS = 2, STAMP_TOTAL = 3,
+  STAMP_FILL = 4, STAMP_SCAN0 = 5, STAMP_EVENTS = 6, STAMP_COMMIT = 7, STAMP_ARENAS = 8, STAMP_N = 9
 };
 
 // Everything one launch needs.  Arrays are SoA with the arena index fastest.
@@ -50,6 +60,8 @@ struct StepArgs {
   long long ctl_stride;              // doubles between consecutive steps' controls
   int n_steps;
   int watch_every;                   // lane pass: overlap watch every 5th column (1 = every column)
+  int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
+  unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]
   int *queue;                        // hybrid: [B] arena indices needing the event pass
   int *queue_count;                  // hybrid: [n_steps] or [1]

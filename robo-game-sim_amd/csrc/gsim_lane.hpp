@@ -191,13 +191,18 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
       }
     }
   }
+  // discmask: bits 0..E-1 = discs whose watch fired, bits 16..21 = first column the wave pass has to
+  // scan; the one-lane pass does not track it (measured: costs more here than the shorter scans save at
+  // n <= 3), the two-lane pass does.  The division guard asks for everything.
   bool watch = guard;
-  discmask = guard ? ~0u : 0u;
+  discmask = 0u;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     watch |= wd[e];
     discmask |= wd[e] ? (1u << e) : 0u;
   }
+  discmask |= 1u << 16;
+  if (guard) discmask = ((1u << E) - 1u) | (1u << 16);
   if (watch) return true;
 
 #pragma unroll
@@ -261,6 +266,7 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
   const double thr_pl = half_extent - kRPlayer - kWatchSlack, thr_pk = half_extent - kRPuck - kWatchSlack;
   const double rpp = 2.0 * kRPlayer + grow, rpk = kRPlayer + kRPuck + grow;
   const double r2_pp = rpp * rpp * (1.0 + kWatchSlack), r2_pk = rpk * rpk * (1.0 + kWatchSlack);
+  int first_col = 0;
   for (int i = 0; i < kGrid; i += we) {
 #pragma nounroll
     for (int j = 0; j < we; ++j) {
@@ -280,12 +286,21 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
         wd[o] |= near;
       }
     }
-  }
-  discmask = guard ? ~0u : 0u;
+    bool any = false;
 #pragma unroll
-  for (int e = 0; e < E; ++e) discmask |= wd[e] ? (1u << e) : 0u;
-  discmask |= quad_xor1_u32(discmask);                      // a wall flag seen by either axis
-  if (discmask != 0u) return true;
+    for (int e = 0; e < E; ++e) any |= wd[e];
+    first_col = (first_col == 0 && any) ? i + 1 : first_col;
+  }
+  unsigned bits = guard ? ((1u << E) - 1u) : 0u;
+#pragma unroll
+  for (int e = 0; e < E; ++e) bits |= wd[e] ? (1u << e) : 0u;
+  bits |= quad_xor1_u32(bits);                              // a wall flag seen by either axis
+  unsigned fc = (unsigned)(first_col < 1 ? kGrid : first_col);           // the earlier of the two lanes' first blocks
+  const unsigned fo = quad_xor1_u32(fc);
+  fc = fo < fc ? fo : fc;
+  if (guard || quad_xor1_u32(guard ? 1u : 0u) != 0u) fc = 1u;
+  discmask = bits | (fc << 16);
+  if (bits != 0u) return true;
 
 #pragma unroll
   for (int e = 0; e < E; ++e) {                             // cpp:153-157, this lane's axis

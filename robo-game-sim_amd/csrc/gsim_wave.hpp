@@ -219,8 +219,10 @@ struct EventSlots {
 
 // Full reference step for arena `a`.  G: this group's LDS region (WaveLayout<N>::DOUBLES).
 // lg: lane index inside the group; gbase: wave lane of the group's lane 0.
-// discmask: discs whose overlap watch fired in the lane pass (all ones when unknown); a disc
-// outside the mask provably has no candidate in the first scan, so that scan is skipped.
+// discmask: bits 0..E-1 = discs whose overlap watch fired in the lane pass (all ones when unknown) --
+// a disc outside the mask provably has no candidate in the first scan, so that scan is skipped;
+// bits 16..21 = first grid column that can hold a candidate (1 when unknown), where the first scans
+// start.
 // Returns without touching anything if the game is already decided (cpp:121-123).
 template <int N, int GW, bool FAST>
 __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a, double *G,
@@ -234,6 +236,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   const double t0 = p.tcur[a];
   const double dt = p.dt, dt_col = p.dt_col;
   double *U = G + L::U_OFF;
+  const bool stamp = GSIM_STAMPS && p.stamps && gbase == 0;               // diagnostic: group 0 times its phases
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  if (stamp) ts0 = __builtin_amdgcn_s_memtime();
 
   // ---- fill: populateStateGrid, cpp:173-217 ----
   if (lg < 2 * E) {
@@ -255,6 +260,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     }
   }
   wave_sync();
+  if (stamp) ts1 = __builtin_amdgcn_s_memtime();
 
   // ---- event loop, cpp:136-150 ----
   EventSlots<E> ev;
@@ -262,14 +268,17 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   int seq = 0, base = 1, counter = 0;
   bool scored = false;
   unsigned n_resolved = 0, n_skipped = 0, n_overflow = 0;
+  int scan_from = (int)((discmask >> 16) & 63u);
+  scan_from = scan_from < 1 ? 1 : (scan_from > kGrid ? kGrid : scan_from);
 #pragma unroll
   for (int id = 0; id < E; ++id) {                           // first pass: checks = all discs, cpp:145
     double tt; int jj, kk;
-    if (((discmask >> id) & 1u) && scan_disc<N, GW>(p, G, id, base, t0, dt, dt_col, lg, gbase, tt, jj, kk))
+    if (((discmask >> id) & 1u) && scan_disc<N, GW>(p, G, id, scan_from, t0, dt, dt_col, lg, gbase, tt, jj, kk))
       ev.put(id, tt, jj, kk, seq++);
   }
   counter = 1;
   const bool had_events = ev.any();
+  if (stamp) ts2 = __builtin_amdgcn_s_memtime();
 
   while (ev.any() && counter < kLoopCap) {
     int ci, cj, ckind;
@@ -395,6 +404,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     }
   }
 
+  if (stamp) ts3 = __builtin_amdgcn_s_memtime();
   // ---- commit: column 50 -> state, t_ += dt_ (cpp:153-158) ----
   if (lg < 2 * E) {
     const int e = lg >> 1, ax = lg & 1;
@@ -414,6 +424,14 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     }
   }
   wave_sync();   // the next step's fill must not overtake this step's column-50 reads
+  if (stamp && lg == 0) {
+    const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&p.stamp_out[STAMP_FILL], ts1 - ts0);
+    atomicAdd(&p.stamp_out[STAMP_SCAN0], ts2 - ts1);
+    atomicAdd(&p.stamp_out[STAMP_EVENTS], ts3 - ts2);
+    atomicAdd(&p.stamp_out[STAMP_COMMIT], ts4 - ts3);
+    atomicAdd(&p.stamp_out[STAMP_ARENAS], 1ull);
+  }
 }
 
 }  // namespace gsim

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   if (a >= p.B) return;
   double *G = lds + (wave * GPW + grp) * L::DOUBLES;
   for (int k = 0; k < p.n_steps; ++k)
-    arena_step_group<N, GW, FAST>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, ~0u);
+    arena_step_group<N, GW, FAST>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
 }
 
 // Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
@@ -76,13 +76,19 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
   const long long a = a0 + lane;
   const bool mine = a < p.B;
   double *G = lds + grp * WaveLayout<N>::DOUBLES;
+  unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
+  if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < p.n_steps; ++k) {
     const double *ctl = p.ctl + (long long)k * p.ctl_stride;
     unsigned discmask = 0u;
+    unsigned long long t0 = 0;
+    if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
     const bool slow = mine && lane_step<N, MODE>(p, ctl, a, discmask);
     unsigned long long m = __ballot(slow);
     if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
     __syncthreads();                                 // lane-pass stores visible to the wave pass
+    unsigned long long t1 = 0;
+    if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
     while (m != 0ull) {                              // GPW flagged arenas per round, one per lane group
       int bit = -1;
       unsigned long long mm = m;
@@ -93,10 +99,18 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
         mm &= mm - 1ull;                             // 0 & anything stays 0
       }
       m = mm;
+      n_rounds++;
       const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
       if (bit >= 0) arena_step_group<N, GW, FAST>(p, ctl, a0 + bit, G, lg, lane - lg, dm);
     }
     __syncthreads();
+    if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
+  }
+  if (GSIM_STAMPS && p.stamps && lane == 0) {
+    atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
+    atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
+    atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
+    atomicAdd(&p.stamp_out[STAMP_TOTAL], __builtin_amdgcn_s_memtime() - t_begin);
   }
 }
 
@@ -233,6 +247,7 @@ struct rgs_sim {
   int win = 3, seed = 0;
   bool fast_div = true;            // cleared by rgs_set_fast_division(0) or by unsuitable taus
   bool sparse_watch = true;        // cleared by rgs_set_sparse_watch(0)
+  bool stamps = false;             // rgs_get_stamps(enable)
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
 };
 
@@ -345,6 +360,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.watch_every = we;
   }
   a.counters = s->counters;
+  a.stamps = s->stamps ? 1 : 0;
+  a.stamp_out = s->counters + CNT_N;
   a.queue = nullptr; a.queue_count = nullptr;
   // AUTO: measured on MI355X (profiles/r01): one lane per arena wins up to 3v3; from 4v4 on its
   // register footprint spills and the two-lanes-per-arena form is faster (4v4 +48 %, 7v7 +11 %).
@@ -408,7 +425,7 @@ int do_reset(rgs_sim *s, const double *x0_host, int batched) {
     }
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemsetAsync(s->counters, 0, CNT_N * sizeof(unsigned long long), s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->counters, 0, (CNT_N + STAMP_N) * sizeof(unsigned long long), s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   hipFree(x0_dev);
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("reset: ") + hipGetErrorString(e));
@@ -448,7 +465,7 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   if (e == hipSuccess) e = hipMalloc(&s->damage, sizeof(double) * s->P * s->P * s->B);
   if (e == hipSuccess) e = hipMalloc(&s->tprev, sizeof(double) * s->B);
   if (e == hipSuccess) e = hipMalloc(&s->ctl, sizeof(double) * s->P * 2 * s->B);
-  if (e == hipSuccess) e = hipMalloc(&s->counters, sizeof(unsigned long long) * CNT_N);
+  if (e == hipSuccess) e = hipMalloc(&s->counters, sizeof(unsigned long long) * (CNT_N + STAMP_N));
   if (e == hipSuccess) e = hipMalloc(&s->flags, (size_t)s->B);
   if (e != hipSuccess) {
     std::string m = std::string("rgs_create: ") + hipGetErrorString(e);
@@ -682,6 +699,19 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out8, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+// Diagnostic: per-phase shader-cycle totals of the one-lane hybrid kernel since the last reset.
+// out4: lane-pass cycles, wave-pass cycles, wave-pass rounds, total kernel cycles (summed over waves).
+int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out4) {  /* out: STAMP_N = 9 values */
+  if (!s) return fail(RGS_ERR_ARG, "rgs_get_stamps: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  s->stamps = enable != 0;
+  if (out4) {
+    HIP_TRY(hipMemcpyAsync(out4, s->counters + CNT_N, sizeof(unsigned long long) * STAMP_N, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   return RGS_OK;
 }
 

@@ -290,6 +290,13 @@ class BatchedGameSim:
         names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps", "flagged"]
         return dict(zip(names, list(out)[:6]))
 
+    def stamps(self, enable=True):
+        """Diagnostic: enable/disable in-kernel phase stamps and return the totals so far."""
+        out = (C.c_int64 * 9)()
+        _lib.check(self._L.rgs_get_stamps(self._h, int(bool(enable)), out))
+        return dict(zip(["lane_cycles", "wave_cycles", "rounds", "total_cycles", "g0_fill", "g0_scan0", "g0_events",
+                         "g0_commit", "g0_arenas"], list(out)))
+
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
 

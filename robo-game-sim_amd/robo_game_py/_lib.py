@@ -53,6 +53,7 @@ SIGNATURES = {
     "rgs_timer_start": (C.c_int, [_vp]),
     "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
     "rgs_set_fast_division": (C.c_int, [_vp, C.c_int]),
     "rgs_set_sparse_watch": (C.c_int, [_vp, C.c_int]),
