@@ -31,7 +31,7 @@ enum {
   RGS_OK = 0,
   RGS_ERR_ARG = -1,          /* bad argument (null, range, n_per_team not in 1..7) */
   RGS_ERR_HIP = -2,          /* a HIP runtime call failed; see rgs_last_error() */
-  RGS_ERR_UNSUPPORTED = -3,  /* feature outside this build (noise > 0) */
+  RGS_ERR_UNSUPPORTED = -3,  /* request outside this build's limits (e.g. noise > 0 with > 4096 arenas) */
   RGS_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
 };
 
@@ -56,8 +56,12 @@ int rgs_destroy(rgs_sim *sim);
 
 /* GameSim::reset (include/GameSim.h:21-24, src/GameSim.cpp:21-55).  log/logname are host-side
  * concerns and live in the Python layer.  x0_ball_host: [4] if !x0_batched else [4][B].
- * noise != 0 returns RGS_ERR_UNSUPPORTED.  `seed` is recorded only (with
- * noise == 0 the reference's seed has no effect on the physics). */
+ * noise != 0 (w_stdev_, src/GameSim.cpp:30,66-67): arena a draws from the reference's own generator
+ * (std::default_random_engine(seed + a) + std::normal_distribution, its cached draw surviving resets
+ * like the reference's w_dist_); the draws are generated on the host and consumed by the one-wave-
+ * per-arena kernel in the reference's call order, so results match the reference bit for bit.  This
+ * mode steps one launch per step and is limited to 4096 arenas per handle (RGS_ERR_UNSUPPORTED
+ * beyond).  With noise == 0 the seed has no effect on the physics. */
 int rgs_reset(rgs_sim *sim, double dt, int winning_score, const double *x0_ball_host, int x0_batched,
               double noise, int seed, double tau_puck, double tau_player, double player_mass,
               double puck_mass);

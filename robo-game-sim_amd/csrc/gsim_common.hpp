@@ -60,6 +60,12 @@ struct StepArgs {
   long long ctl_stride;              // doubles between consecutive steps' controls
   int n_steps;
   int watch_every;                   // lane pass: overlap watch every 5th column (1 = every column)
+  // noise > 0 (wave kernel only): w_stdev_ (cpp:30) and the per-arena tape of N(0,1) draws the host
+  // generated with the reference's own engine/distribution (cpp:3,41,66-67); tape[a*tape_len + k].
+  double sigma;
+  const double *tape;
+  int tape_len;
+  int *consumed;                     // [B] draws used by this step (> tape_len: tape too short, redo)
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]
@@ -138,6 +144,30 @@ __device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double
   const double w = h / 6.0;
   Chain r;
   r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;   // cpp:87
+  r.v = x.v + (__builtin_fma(k3v, 2.0, __builtin_fma(k2v, 2.0, k1v)) + k4v) * w;
+  return r;
+}
+
+// RK4_player with the noise term of f_player (cpp:62-88): xdot_v = (u - v)/tau + w_stdev * N(0,1), two
+// draws per f_player call in the order vx, vy, i.e. this axis' draw of stage s is nz[2*s].  The puck
+// passes sigma = 0 (f_puck draws nothing; adding +0.0 changes no value).  IEEE division.
+__device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, double tau, double h, double sigma,
+                                                const double *nz) {
+  const double half = h / 2.0;
+  const double k1p = x.v;
+  const double k1v = (u - coef * x.v) / tau + sigma * nz[0];
+  const double x2v = x.v + k1v * half;
+  const double k2p = x2v;
+  const double k2v = (u - coef * x2v) / tau + sigma * nz[2];
+  const double x3v = x.v + k2v * half;
+  const double k3p = x3v;
+  const double k3v = (u - coef * x3v) / tau + sigma * nz[4];
+  const double x4v = x.v + k3v * h;
+  const double k4p = x4v;
+  const double k4v = (u - coef * x4v) / tau + sigma * nz[6];
+  const double w = h / 6.0;
+  Chain r;
+  r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;
   r.v = x.v + (__builtin_fma(k3v, 2.0, __builtin_fma(k2v, 2.0, k1v)) + k4v) * w;
   return r;
 }

@@ -224,7 +224,14 @@ struct EventSlots {
 // bits 16..21 = first grid column that can hold a candidate (1 when unknown), where the first scans
 // start.
 // Returns without touching anything if the game is already decided (cpp:121-123).
-template <int N, int GW, bool FAST>
+//
+// NOISE (w_stdev_ != 0): every RK4 of a player consumes 8 draws of the arena's tape in the reference's
+// call order -- populateStateGrid: column by column, A1..Bn (cpp:199-215); carryOutFirstCollision:
+// disc i then disc j to the impact instant, i then j for the remainder, then i, j per re-integrated
+// column (cpp:255-256, 287-288, 294-295 / 309, 331, 338); the puck draws nothing.  `cur` is that
+// cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
+// step with a longer tape.
+template <int N, int GW, bool FAST, bool NOISE = false>
 __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a, double *G,
                                  int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
@@ -236,6 +243,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   const double t0 = p.tcur[a];
   const double dt = p.dt, dt_col = p.dt_col;
   double *U = G + L::U_OFF;
+  const double *tape = NOISE ? p.tape + a * (long long)p.tape_len : nullptr;
+  const int tape_last = NOISE ? p.tape_len - 8 : 0;         // last legal start of an 8-draw record
+  int cur = 0;                                              // draws consumed so far (group-uniform)
   const bool stamp = GSIM_STAMPS && p.stamps && gbase == 0;               // diagnostic: group 0 times its phases
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
   if (stamp) ts0 = __builtin_amdgcn_s_memtime();
@@ -253,12 +263,18 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     G[4 * e + ax] = x.p;
     G[4 * e + 2 + ax] = x.v;
     const bool fast = FAST && fast_division_safe(u, x.v);
+    const double sg = e != PK ? p.sigma : 0.0;
     for (int i = 1; i <= kGrid; ++i) {
+      if (NOISE) {
+        const int c0 = 8 * ((i - 1) * L::P + (e != PK ? e : 0));
+        x = rk4_axis_noise(x, u, coef, tau, dt_col, sg, tape + (c0 < tape_last ? c0 : tape_last) + ax);
+      } else
       x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);
       G[i * CS + 4 * e + ax] = x.p;
       G[i * CS + 4 * e + 2 + ax] = x.v;
     }
   }
+  if (NOISE) cur = 8 * kGrid * L::P;
   wave_sync();
   if (stamp) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -307,6 +323,17 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       x.p = G[(base - 1) * CS + 4 * d + ax];
       x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
       bool fast = FAST && fast_division_safe(u, x.v);
+      // noise bookkeeping: np players among the event's discs draw; this lane's disc is the slot-th of them
+      const int np = NOISE ? ((ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0)) : 0;
+      const int slot = (is_pair && !first && ci != PK) ? 1 : 0;
+      const double sg = (NOISE && d != PK) ? p.sigma : 0.0;
+      int call = 0;                                          // this disc's RK4 calls so far in this event
+      auto noisy = [&](Chain xx, double hh) {
+        const int c0 = cur + 8 * (call * np + slot);
+        ++call;
+        return rk4_axis_noise(xx, u, coef, tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + ax);
+      };
+      if (NOISE) x = noisy(x, dt_t); else
       x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_t, fast);   // cpp:255-256, 309
 
       // pair constants (unused for walls)
@@ -360,11 +387,16 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       fast = FAST && fast_division_safe(u, x.v);             // the velocity just changed
       if (goal) {
         x.p = 0.0; x.v = 0.0;                                // cpp:325
+      } else if (NOISE) {
+        x = noisy(x, dt_col - dt_t);
       } else {
         x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col - dt_t, fast);   // cpp:287-288, 331
       }
       for (int g = base; g <= kGrid; ++g) {
-        if (g > base) x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);   // cpp:294-295, 338
+        if (g > base) {
+          if (NOISE) x = noisy(x, dt_col); else
+          x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);   // cpp:294-295, 338
+        }
         if (is_pair) {                                       // correctOverlap(i, j), cpp:581-592
           const double po = quad_xor2(x.p);
           const double pij = first ? po - x.p : x.p - po;
@@ -389,6 +421,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       }
     }
     goal = __shfl(goal ? 1 : 0, gbase) != 0;
+    if (NOISE) {                                             // calls per drawing disc: impact, remainder (not after a goal), columns
+      const int np_ev = (ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0);
+      cur += 8 * np_ev * ((goal ? 1 : 2) + (kGrid - base));
+    }
     if (goal) {                                              // cpp:324-326
       if (!scored) { if (ckind == RIGHT) TAS += 1.0; else TBS += 1.0; }
       scored = true;
@@ -413,6 +449,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     p.state[(long long)(row + 2 + ax) * B + a] = G[kGrid * CS + 4 * e + 2 + ax];
   }
   if (lg == 0) {
+    if (NOISE) p.consumed[a] = cur;
     p.tcur[a] = t0 + dt;
     if (scored) { p.state[0 * B + a] = TAS; p.state[1 * B + a] = TBS; }
     if (had_events) {

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <random>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,7 +40,7 @@ constexpr int kWavesPerBlock = 4;
 
 // One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
 // the SoA arrays (L2-resident) between steps.
-template <int N, int GW, bool FAST>
+template <int N, int GW, bool FAST, bool NOISE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   if (a >= p.B) return;
   double *G = lds + (wave * GPW + grp) * L::DOUBLES;
   for (int k = 0; k < p.n_steps; ++k)
-    arena_step_group<N, GW, FAST>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
+    arena_step_group<N, GW, FAST, NOISE>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
 }
 
 // Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
@@ -248,6 +249,17 @@ struct rgs_sim {
   bool fast_div = true;            // cleared by rgs_set_fast_division(0) or by unsuitable taus
   bool sparse_watch = true;        // cleared by rgs_set_sparse_watch(0)
   bool stamps = false;             // rgs_get_stamps(enable)
+  // noise > 0: the reference's generator per arena, src/GameSim.cpp:3,41 -- the engine is
+  // re-seeded by reset(), the distribution (with its cached second draw) deliberately is not.
+  double sigma = 0.0;
+  std::vector<std::default_random_engine> reng;
+  std::vector<std::normal_distribution<double>> wdist;
+  std::vector<double> tape_host;
+  std::vector<int> consumed_host;
+  double *tape_dev = nullptr, *bak_state = nullptr, *bak_tcur = nullptr, *bak_damage = nullptr;
+  int *consumed_dev = nullptr;
+  unsigned long long *bak_counters = nullptr;
+  size_t tape_cap = 0;             // doubles allocated in tape_dev
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
 };
 
@@ -298,6 +310,83 @@ int launch_wave(rgs_sim *s, const StepArgs &args) {
     hipLaunchKernelGGL((k_step_wave<N, GW, false>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave launch: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
+template <int N>
+int launch_wave_noise(rgs_sim *s, const StepArgs &args) {
+  const long long blocks = (s->B + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * kWavesPerBlock;
+  hipLaunchKernelGGL((k_step_wave<N, 64, false, true>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave<noise> launch: ") + hipGetErrorString(e));
+  return RGS_OK;
+}
+
+constexpr long long kNoiseMaxArenas = 4096;     // tapes are host-generated and uploaded every step
+
+// One step with w_stdev_ != 0.  The host draws a tape of N(0,1) values per arena from COPIES of the
+// arena's generator, the wave kernel consumes them in the reference's call order and reports how many
+// it used, and the real generators are then advanced by exactly that many draws.  A step whose events
+// need more draws than the first, short tape holds is redone from a backup with the worst-case length.
+int noise_step(rgs_sim *s, StepArgs a) {
+  const long long B = s->B;
+  const int P = s->P;
+  const int base_draws = 8 * kGrid * P;
+  const int per_event = 8 * 2 * (kGrid + 3);
+  const int lens[2] = {base_draws + 6 * per_event, base_draws + (kLoopCap - 1) * per_event};
+  HIP_TRY(hipMemcpyAsync(s->bak_state, s->state, sizeof(double) * s->S * B, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->bak_tcur, s->tcur, sizeof(double) * B, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->bak_damage, s->damage, sizeof(double) * P * P * B, hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->bak_counters, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToDevice, s->stream));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int T = lens[attempt];
+    const size_t need = (size_t)T * (size_t)B;
+    if (need > s->tape_cap) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      hipFree(s->tape_dev);
+      s->tape_dev = nullptr;
+      HIP_TRY(hipMalloc(&s->tape_dev, sizeof(double) * need));
+      s->tape_cap = need;
+    }
+    s->tape_host.resize(need);
+    for (long long ar = 0; ar < B; ++ar) {
+      std::default_random_engine e = s->reng[ar];              // copies: the originals advance later
+      std::normal_distribution<double> d = s->wdist[ar];
+      double *t = s->tape_host.data() + (size_t)ar * T;
+      for (int k = 0; k < T; ++k) t[k] = d(e);                 // w_dist_(reng_), src/GameSim.cpp:66-67
+    }
+    HIP_TRY(hipMemcpyAsync(s->tape_dev, s->tape_host.data(), sizeof(double) * need, hipMemcpyHostToDevice, s->stream));
+    a.tape = s->tape_dev; a.tape_len = T; a.sigma = s->sigma; a.consumed = s->consumed_dev;
+    a.n_steps = 1; a.ctl_stride = 0;
+    HIP_TRY(hipMemsetAsync(s->consumed_dev, 0, sizeof(int) * B, s->stream));   // decided arenas draw nothing
+    int rc = RGS_ERR_ARG;
+    switch (s->n) {
+      case 1: rc = launch_wave_noise<1>(s, a); break;
+      case 2: rc = launch_wave_noise<2>(s, a); break;
+      case 3: rc = launch_wave_noise<3>(s, a); break;
+      case 4: rc = launch_wave_noise<4>(s, a); break;
+      case 5: rc = launch_wave_noise<5>(s, a); break;
+      case 6: rc = launch_wave_noise<6>(s, a); break;
+      case 7: rc = launch_wave_noise<7>(s, a); break;
+    }
+    if (rc != RGS_OK) return rc;
+    s->consumed_host.resize(B);
+    HIP_TRY(hipMemcpyAsync(s->consumed_host.data(), s->consumed_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    bool overflow = false;
+    for (long long ar = 0; ar < B; ++ar) overflow |= s->consumed_host[ar] > T;
+    if (!overflow) {
+      for (long long ar = 0; ar < B; ++ar)
+        for (int k = 0; k < s->consumed_host[ar]; ++k) (void)s->wdist[ar](s->reng[ar]);
+      return RGS_OK;
+    }
+    if (attempt == 1) return fail(RGS_ERR_HIP, "noise_step: worst-case tape still too short (internal error)");
+    HIP_TRY(hipMemcpyAsync(s->state, s->bak_state, sizeof(double) * s->S * B, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->tcur, s->bak_tcur, sizeof(double) * B, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->damage, s->bak_damage, sizeof(double) * P * P * B, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->counters, s->bak_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToDevice, s->stream));
+  }
   return RGS_OK;
 }
 
@@ -363,6 +452,15 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.queue = nullptr; a.queue_count = nullptr;
+  a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr;
+  if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
+    for (int k = 0; k < n_steps; ++k) {
+      a.ctl = ctl_dev + (long long)k * stride;
+      int rc = noise_step(s, a);
+      if (rc != RGS_OK) return rc;
+    }
+    return RGS_OK;
+  }
   // AUTO: measured on MI355X (profiles/r01): one lane per arena wins up to 3v3; from 4v4 on its
   // register footprint spills and the two-lanes-per-arena form is faster (4v4 +48 %, 7v7 +11 %).
   const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->n >= 4 ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID);
@@ -483,7 +581,8 @@ int rgs_destroy(rgs_sim *s) {
   if (!s) return RGS_OK;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  hipFree(s->state); hipFree(s->tcur); hipFree(s->tprev); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
+  hipFree(s->state); hipFree(s->tcur); hipFree(s->tprev);
+  hipFree(s->tape_dev); hipFree(s->bak_state); hipFree(s->bak_tcur); hipFree(s->bak_damage); hipFree(s->consumed_dev); hipFree(s->bak_counters); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -494,8 +593,22 @@ int rgs_destroy(rgs_sim *s) {
 int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_host, int x0_batched, double noise,
               int seed, double tau_puck, double tau_player, double player_mass, double puck_mass) {
   if (!s || !x0_ball_host) return fail(RGS_ERR_ARG, "rgs_reset: null argument");
-  if (noise != 0.0)
-    return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 is not implemented on the device (SURVEY 8f-3)");
+  if (noise != 0.0) {
+    if (s->B > kNoiseMaxArenas)
+      return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 needs host-generated draw tapes and is limited to 4096 arenas per handle");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->bak_state) {
+      HIP_TRY(hipMalloc(&s->bak_state, sizeof(double) * s->S * s->B));
+      HIP_TRY(hipMalloc(&s->bak_tcur, sizeof(double) * s->B));
+      HIP_TRY(hipMalloc(&s->bak_damage, sizeof(double) * s->P * s->P * s->B));
+      HIP_TRY(hipMalloc(&s->consumed_dev, sizeof(int) * s->B));
+      HIP_TRY(hipMalloc(&s->bak_counters, sizeof(unsigned long long) * CNT_N));
+    }
+    s->reng.resize(s->B);
+    s->wdist.resize(s->B, std::normal_distribution<double>(0.0, 1.0));   // kept across resets, cpp:41
+    for (long long ar = 0; ar < s->B; ++ar) s->reng[ar] = std::default_random_engine(seed + (int)ar);   // cpp:41
+  }
+  s->sigma = noise;
   s->dt = dt;
   s->dt_col = dt / kGrid;                        // cpp:28
   s->win = winning_score;

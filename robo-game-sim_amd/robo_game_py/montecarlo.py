@@ -122,15 +122,14 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
     Returns dict(state (S, B), scores (2, B), damage (P, P, B), undecided (B,), steps).
     """
     B = int(mc_params.num_runs)
-    if float(mc_params.noise_stdev) != 0.0:
-        raise ValueError("noise_stdev != 0 is not implemented on the device (SURVEY 8f-3)")
     own = sim is None
     sim = sim or BatchedGameSim(B, n_per_team, device)
     P = sim.players
     seeds = np.arange(1, B + 1)                                             # py/MonteCarlo.py:23,29
     write_configuration(mc_params)
-    sim.reset(mc_params.dt, mc_params.winning_score, np.asarray(mc_params.x0_ball, dtype=np.float64), 0.0, False, "",
-              0, mc_params.tau_puck, mc_params.tau_player, mc_params.player_mass, mc_params.puck_mass)
+    # run i of the reference uses seed = i (py/MonteCarlo.py:29); arena a draws from seed + a, so seed = 1
+    sim.reset(mc_params.dt, mc_params.winning_score, np.asarray(mc_params.x0_ball, dtype=np.float64),
+              float(mc_params.noise_stdev), False, "", 1, mc_params.tau_puck, mc_params.tau_player, mc_params.player_mass, mc_params.puck_mass)
     N = steps_per_run(mc_params)
     runs = list(range(1, B + 1)) if logged_runs is None else [int(r) for r in logged_runs]
     files = {}

@@ -341,8 +341,49 @@ def test_full_size_batch_is_shard_invariant(rgp):
         sub.close()
 
 
-def test_noise_is_refused_not_faked(rgp):
-    sim = rgp.BatchedGameSim(4, 2)
+def test_noise_matches_reference_generator_single_game(rgp, oracle):
+    """noise > 0 through the drop-in GameSim: same libstdc++ engine/distribution stream, consumed in the
+    reference's call order (fill, then every re-integration), incl. the w_dist_ that survives reset()."""
+    Z = np.zeros(2)
+    g, o = rgp.GameSim(), oracle.OracleGameSim()
+    rng = np.random.default_rng(3)
+    for seed, noise, x0 in ((7, 0.3, [0.5, 0.2, 3.0, 1.0]), (11, 2.0, [-2.0, 1.0, -4.0, 2.0]), (0, 0.05, [0, 0, 0, 0])):
+        sg = g.reset(0.05, 3, np.array(x0, dtype=float), noise, False, "", seed, 0.1, 0.5, 1.0, 0.5)
+        so = o.reset(0.05, 3, np.array(x0, dtype=float), noise, False, "", seed, 0.1, 0.5, 1.0, 0.5)
+        assert np.array_equal(sg, so)
+        for k in range(120):
+            u = [rng.uniform(-8, 8, 2) for _ in range(4)]
+            sg, so = g.run(*u), o.run(*u)
+            assert np.array_equal(sg, so), "seed %d step %d: max |delta| %g" % (seed, k, np.max(np.abs(sg - so)))
+        assert g.undecided() == o.undecided()
+    assert o.stats()["resolved"] > 10                       # collisions happened, so re-integration draws were used
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_noise_batched_with_many_events(rgp, oracle, n):
+    """Batched noise: arena a uses seed + a; chase play forces steps with more events than the first,
+    short draw tape holds, which exercises the redo-with-a-longer-tape path."""
+    from robo_game_py import workloads as w
+    B, K, dt = 48, 80, 0.05
+    x0, _, _ = w.c2_inputs(B, n, seed=9)
+    sim = rgp.BatchedGameSim(B, n)
+    state = sim.reset(dt, 3, x0, 0.4, False, "", 100, 0.1, 0.5, 1.0, 0.5)
+    osims = [oracle.OracleGameSim(n) for _ in range(B)]
+    for a, o in enumerate(osims):
+        o.reset(dt, 3, x0[:, a], 0.4, False, "", 100 + a, 0.1, 0.5, 1.0, 0.5)
+    for k in range(K):
+        u = w.chase_controls(state, n)
+        state = sim.run(u)
+        ost = np.stack([o.run(np.ascontiguousarray(u[:, :, a])) for a, o in enumerate(osims)], axis=1)
+        assert_same(state, ost, "noise chase n=%d step %d" % (n, k))
+    assert_same(sim.damage(), np.stack([o.damage() for o in osims], axis=2), "damage")
+    caps = sum(o.stats()["cap_hits"] for o in osims)
+    assert sim.counters()["cap_hits"] == caps and caps > 0   # 49-event steps need the worst-case tape
+    sim.close()
+
+
+def test_noise_is_limited_not_faked(rgp):
+    sim = rgp.BatchedGameSim(5000, 2)
     with pytest.raises(rgp.RgsError):
         sim.reset(0.05, 3, np.zeros(4), 0.1)
     sim.close()
