@@ -217,6 +217,28 @@ def test_reference_sample_values_through_dropin(rgp):
     assert np.array_equal(st1, st2)
 
 
+def test_c1_run_sim_loop_100_seconds(rgp, oracle):
+    """BASELINE config C1: one 2v2 arena, 100 s at dt = 0.01, mindless controls, driven exactly like
+    py/run_sim.py:43-75 (reset, one zero-input run, `while t < T: ...; t += dt` in float64) through the
+    drop-in GameSim, against the oracle step by step."""
+    from math import cos, sin
+    args = (0.01, 4, np.array([-1.0, 0.0, 0.0, 0.0]), 0.0, False, "", 0, 0.1, 0.5, 1.0, 0.5)
+    g, o = rgp.GameSim(), oracle.OracleGameSim()
+    assert np.array_equal(g.reset(*args), o.reset(*args))
+    z = np.zeros(2)
+    assert np.array_equal(g.run(z, z, z, z), o.run(z, z, z, z))
+    t, steps = 0.0, 0
+    while t < 100.0:
+        u = np.array([cos(t), sin(t)])
+        sg, so = g.run(u, u, u, u), o.run(u, u, u, u)
+        if steps % 97 == 0 or t + 0.01 >= 100.0:
+            assert np.array_equal(sg, so), "step %d: max |delta| %g" % (steps, np.max(np.abs(sg - so)))
+        t += 0.01
+        steps += 1
+    assert steps in (10000, 10001) and np.array_equal(sg, so)
+    assert g.time() == o.time() and g.undecided() == o.undecided()
+
+
 VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid"), pytest.param(3, id="hybrid2")]
 
 
