@@ -13,6 +13,9 @@
 // Diagnostic in-kernel phase stamps (s_memtime).  Compiled out by default: even as never-taken
 // run-time branches they cost the one-lane hybrid kernel 2.7 % (measured).  `make STAMPS=1` builds
 // the diagnostic library; rgs_get_stamps() then returns the phase totals.
+#ifndef GSIM_WIDE_GROUPS
+#define GSIM_WIDE_GROUPS 0
+#endif
 #ifndef GSIM_STAMPS
 #define GSIM_STAMPS 0
 #endif

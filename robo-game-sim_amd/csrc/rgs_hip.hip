@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
 // (disc, axis) chains, so 4 (n <= 3) or 2 (n >= 4) flagged arenas are re-run side by side.
 template <int N>
 struct HybridGroups {
-  static constexpr int GW = (2 * (2 * N + 1) <= 16) ? 16 : 32;
+  static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16 : 32;
   static constexpr int GPW = 64 / GW;
 };
 
