@@ -135,20 +135,28 @@ int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out9);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
 
-/* The lane pass divides by tau_player / tau_puck with a reciprocal-plus-two-corrections sequence
- * that is proven and tested to round exactly like IEEE '/'.  enable = 0 forces the
- * compiler's IEEE division everywhere (slower, same results); taus outside the proof's domain
- * select it automatically. */
-int rgs_set_fast_division(rgs_sim *sim, int enable);
+/* Divisions by tau_player / tau_puck use reciprocal sequences that round exactly like IEEE '/'
+ * ("Division by tau"): a multiply when tau is a power of two; reciprocal + ONE correction
+ * step when the host has certified tau for it (all worst-case dividends enumerated and checked at
+ * reset); reciprocal + two correction steps (proven for any tau in the domain) otherwise.
+ * level: 0 = IEEE '/' everywhere, 1 = never the one-step form, 2 = everything allowed (default).
+ * Taus outside the domain select IEEE automatically.  All levels give identical results. */
+int rgs_set_fast_division(rgs_sim *sim, int level);
+
+/* What the host decides for a given tau: *fast_ok (in the reciprocal domain), *pow2, *one_step
+ * (certified).  worst_out (may be NULL) receives up to worst_cap of the enumerated worst-case
+ * dividends (quotients within 2^-51 ulp of a rounding midpoint), *worst_count their number. */
+int rgs_division_info(double tau, int *fast_ok, int *pow2, int *one_step, double *worst_out, int worst_cap,
+                      int *worst_count);
 
 /* The lane pass evaluates the disc-pair part of its (conservative) overlap watch every 5th sub-step
  * against radii widened by the largest possible travel in between; enable = 0 evaluates it at every
  * sub-step (slower, same results).  Batches with dt_col/tau > 0.1 use every sub-step automatically. */
 int rgs_set_sparse_watch(rgs_sim *sim, int enable);
 
-/* fast[i] = a[i]/tau by the reciprocal sequence, ieee[i] = a[i]/tau by IEEE '/', both on the GPU. */
+/* a[i]/tau on the GPU three ways: two-step reciprocal (fast), IEEE '/', one-step reciprocal (one). */
 int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double tau, double *fast_host,
-                        double *ieee_host);
+                        double *ieee_host, double *one_host);
 
 /* Device arithmetic self-test: computes a[i]/b[i] and sqrt(a[i]) on the GPU with the same
  * code paths the stepper uses, for comparison with the host's IEEE results. */

@@ -112,9 +112,22 @@ struct Chain {
 //   fast_division_ok); a == 0 or 2^-760 <= |a| <= 2^520 so r1 never underflows (lane_step's
 //   entry guard).  DESIGN.md "Division by tau" has the full argument; rgs_selftest_divtau and
 //   tests/test_gpu_parity.py check it against IEEE '/' on adversarial near-midpoint inputs.
-template <bool FAST>
+// DM: 0 = IEEE '/', 1 = the five steps above, 2 = tau is +-2^k so a*(1/tau) is the exact quotient,
+// 3 = ONE correction step (q1 above), used only for taus the host has certified: q1 = RN(a/tau + d)
+// with |d| < 2^-51 ulp, so q1 can differ from RN(a/tau) only if a/tau lies within 2^-51 ulp of a
+// rounding midpoint, i.e. for significands A of a with |A*2^53 - M*B| <= 7 (A >= B) or
+// |A*2^54 - M*B| <= 7 (A < B), M odd; for a given tau those finitely many A are enumerated by modular
+// inverse and each is checked on the host (one_step_certified, rgs_hip.hip).  A power-of-two tau is
+// trivially fine (r0 = 0).  (bool template arguments still work: false = 0, true = 1.)
+template <int DM>
 __device__ __forceinline__ double div_tau(double a, double tau, double inv) {
-  if (FAST) {
+  if (DM == 2) return a * inv;
+  if (DM == 3) {
+    const double q0 = a * inv;
+    const double r0 = __builtin_fma(-tau, q0, a);
+    return __builtin_fma(r0, inv, q0);
+  }
+  if (DM == 1) {
     const double q0 = a * inv;
     const double r0 = __builtin_fma(-tau, q0, a);
     const double q1 = __builtin_fma(r0, inv, q0);
@@ -130,20 +143,20 @@ __device__ __forceinline__ double div_tau(double a, double tau, double inv) {
 // The position rows of x2..x4 never feed f, so only their velocity rows exist here.
 // cpp:87 combines x + (k1 + k2*2 + k3*2 + k4)*(dt/6); k*2 is exact, so fma(k, 2, acc) rounds
 // exactly once like the reference's multiply-then-add and is bit-identical to it.
-template <bool FAST>
+template <int DM>
 __device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double tau, double inv, double h) {
   const double half = h / 2.0;
   const double k1p = x.v;
-  const double k1v = div_tau<FAST>(u - coef * x.v, tau, inv);
+  const double k1v = div_tau<DM>(u - coef * x.v, tau, inv);
   const double x2v = x.v + k1v * half;
   const double k2p = x2v;
-  const double k2v = div_tau<FAST>(u - coef * x2v, tau, inv);
+  const double k2v = div_tau<DM>(u - coef * x2v, tau, inv);
   const double x3v = x.v + k2v * half;
   const double k3p = x3v;
-  const double k3v = div_tau<FAST>(u - coef * x3v, tau, inv);
+  const double k3v = div_tau<DM>(u - coef * x3v, tau, inv);
   const double x4v = x.v + k3v * h;
   const double k4p = x4v;
-  const double k4v = div_tau<FAST>(u - coef * x4v, tau, inv);
+  const double k4v = div_tau<DM>(u - coef * x4v, tau, inv);
   const double w = h / 6.0;
   Chain r;
   r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;   // cpp:87

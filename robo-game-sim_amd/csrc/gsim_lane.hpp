@@ -29,7 +29,7 @@ constexpr double kWatchSlack = 1.0e-9;
 // loop over the chains, so consecutive instructions belong to different chains and a single
 // wave per SIMD (65 536 arenas = 1024 waves = one per SIMD) still issues back to back instead
 // of waiting out each dependent fp64 latency.  Arithmetic per chain is exactly rk4_axis<FAST>.
-enum DivMode : int { DIV_IEEE = 0, DIV_MARKSTEIN = 1, DIV_PLAYER_POW2 = 2 };
+enum DivMode : int { DIV_IEEE = 0, DIV_MARKSTEIN = 1, DIV_PLAYER_POW2 = 2, DIV_POW2_ONESTEP = 3 };
 
 // The batch is chains [C0, C0 + M) of the arena's arrays; chains >= PKC belong to the puck.
 template <int MODE, int C0, int M, int PKC>
@@ -51,14 +51,22 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 //   DIV_PLAYER_POW2  tau_player is +-2^k (the default 0.5): a/tau = a*(1/tau) exactly -- scaling by a
 //                 power of two is exact and rounds like '/' even into the denormals -- so the 2P
 //                 player chains need one multiply; the puck chains use the five steps.
+//   DIV_POW2_ONESTEP the same, and tau_puck is host-certified for div_tau<3>: three steps for the puck.
 #define GSIM_DIV_MARK(COND)                                                                          \
   _Pragma("unroll") GSIM_EACH if (COND) q[c] = a[c] * GSIM_INV(c);                                    \
   _Pragma("unroll") GSIM_EACH if (COND) r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);               \
   _Pragma("unroll") GSIM_EACH if (COND) q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);                \
   _Pragma("unroll") GSIM_EACH if (COND) r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);               \
   _Pragma("unroll") GSIM_EACH if (COND) q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);
+#define GSIM_DIV_ONE(COND)                                                                           \
+  _Pragma("unroll") GSIM_EACH if (COND) q[c] = a[c] * GSIM_INV(c);                                    \
+  _Pragma("unroll") GSIM_EACH if (COND) r[c] = __builtin_fma(-GSIM_TAU(c), q[c], a[c]);               \
+  _Pragma("unroll") GSIM_EACH if (COND) q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);
 #define GSIM_DIV()                                                                                    \
-  if (MODE == DIV_PLAYER_POW2) {                                                                      \
+  if (MODE == DIV_POW2_ONESTEP) {                                                                     \
+    _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c] * inv_pl;                             \
+    GSIM_DIV_ONE(GSIM_IS_PK(c))                                                                       \
+  } else if (MODE == DIV_PLAYER_POW2) {                                                               \
     _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c] * inv_pl;                             \
     GSIM_DIV_MARK(GSIM_IS_PK(c))                                                                      \
   } else if (MODE == DIV_MARKSTEIN) {                                                                 \
@@ -98,6 +106,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
   GSIM_EACH { p[c] = p[c] + accp[c] * w; v[c] = v[c] + (accv[c] + q[c]) * w; }   // cpp:87
 #undef GSIM_DIV
 #undef GSIM_DIV_MARK
+#undef GSIM_DIV_ONE
 #undef GSIM_IS_PK
 #undef GSIM_COEF
 #undef GSIM_INV

@@ -47,13 +47,14 @@ __device__ __forceinline__ bool fast_division_safe(double u, double v) {
   return u_ok && v_ok && (au <= hi) && (av <= hi);
 }
 
-// rk4_axis with the division flavour chosen per chain at run time (FAST kernels only).
-template <bool FAST>
+// rk4_axis with the division flavour chosen per chain at run time.  FAST: 0 = IEEE only, 1 = two
+// correction steps, 3 = one (host-certified taus); `fast` = this chain's magnitudes are in the window.
+template <int FAST>
 __device__ __forceinline__ Chain rk4_dyn(Chain x, double u, double coef, double tau, double inv, double h, bool fast) {
-  if (FAST) {
-    if (fast) return rk4_axis<true>(x, u, coef, tau, inv, h);
+  if (FAST != 0) {
+    if (fast) return rk4_axis<FAST>(x, u, coef, tau, inv, h);
   }
-  return rk4_axis<false>(x, u, coef, tau, inv, h);
+  return rk4_axis<0>(x, u, coef, tau, inv, h);
 }
 
 template <int GW>
@@ -231,7 +232,7 @@ struct EventSlots {
 // column (cpp:255-256, 287-288, 294-295 / 309, 331, 338); the puck draws nothing.  `cur` is that
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
-template <int N, int GW, bool FAST, bool NOISE = false>
+template <int N, int GW, int FAST, bool NOISE = false>
 __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a, double *G,
                                  int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
@@ -262,7 +263,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     U[2 * e + ax] = u;
     G[4 * e + ax] = x.p;
     G[4 * e + 2 + ax] = x.v;
-    const bool fast = FAST && fast_division_safe(u, x.v);
+    const bool fast = FAST != 0 && fast_division_safe(u, x.v);
     const double sg = e != PK ? p.sigma : 0.0;
     for (int i = 1; i <= kGrid; ++i) {
       if (NOISE) {
@@ -322,7 +323,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       Chain x;
       x.p = G[(base - 1) * CS + 4 * d + ax];
       x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
-      bool fast = FAST && fast_division_safe(u, x.v);
+      bool fast = FAST != 0 && fast_division_safe(u, x.v);
       // noise bookkeeping: np players among the event's discs draw; this lane's disc is the slot-th of them
       const int np = NOISE ? ((ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0)) : 0;
       const int slot = (is_pair && !first && ci != PK) ? 1 : 0;
@@ -384,7 +385,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
         const double py = quad_lane1(x.p);
         goal = d == PK && (ckind == LEFT || ckind == RIGHT) && py < kGoalH / 2.0 && py > -kGoalH / 2.0;  // cpp:321-322
       }
-      fast = FAST && fast_division_safe(u, x.v);             // the velocity just changed
+      fast = FAST != 0 && fast_division_safe(u, x.v);        // the velocity just changed
       if (goal) {
         x.p = 0.0; x.v = 0.0;                                // cpp:325
       } else if (NOISE) {

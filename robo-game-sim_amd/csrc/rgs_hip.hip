@@ -40,7 +40,7 @@ constexpr int kWavesPerBlock = 4;
 
 // One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
 // the SoA arrays (L2-resident) between steps.
-template <int N, int GW, bool FAST, bool NOISE = false>
+template <int N, int GW, int FAST, bool NOISE = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
@@ -68,7 +68,7 @@ struct HybridGroups {
 
 template <int N, int MODE>
 __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
-  constexpr bool FAST = MODE != DIV_IEEE;
+  constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   const int lane = threadIdx.x;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
 // Hybrid with two lanes per arena (gsim_lane.hpp, lane_step_split): 32 arenas per wave.
 template <int N, int MODE>
 __global__ __launch_bounds__(64) void k_step_hybrid2(StepArgs p) {
-  constexpr bool FAST = MODE != DIV_IEEE;
+  constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   const int lane = threadIdx.x;
@@ -213,11 +213,13 @@ __global__ void k_undecided(const double *state, long long B, double win, uint8_
   out[a] = (state[a] < win && state[B + a] < win) ? 1 : 0;
 }
 
-__global__ void k_selftest_divtau(const double *a, long long n, double tau, double inv, double *fast, double *ieee) {
+__global__ void k_selftest_divtau(const double *a, long long n, double tau, double inv, double *fast, double *ieee,
+                                  double *one) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fast[i] = div_tau<true>(a[i], tau, inv);
-  ieee[i] = div_tau<false>(a[i], tau, inv);
+  fast[i] = div_tau<1>(a[i], tau, inv);
+  ieee[i] = div_tau<0>(a[i], tau, inv);
+  one[i] = div_tau<3>(a[i], tau, inv);
 }
 
 __global__ void k_selftest(const double *a, const double *b, long long n, double *q, double *s) {
@@ -249,6 +251,8 @@ struct rgs_sim {
   bool fast_div = true;            // cleared by rgs_set_fast_division(0) or by unsuitable taus
   bool sparse_watch = true;        // cleared by rgs_set_sparse_watch(0)
   bool stamps = false;             // rgs_get_stamps(enable)
+  bool one_step_ok = false;        // both taus pass one_step_certified (set by reset)
+  bool one_step_enabled = true;    // rgs_set_fast_division(2) = allow, (1) = two steps only
   // noise > 0: the reference's generator per arena, src/GameSim.cpp:3,41 -- the engine is
   // re-seeded by reset(), the distribution (with its cached second draw) deliberately is not.
   double sigma = 0.0;
@@ -284,6 +288,66 @@ bool is_power_of_two(double tau) {
   return std::fabs(std::frexp(tau, &e)) == 0.5;
 }
 
+// ---- certification of div_tau<3> (one correction step) for a given tau --------------------------
+// See gsim_common.hpp: the one-step quotient can only be wrong for dividends with significand A such
+// that |A*2^sh - M*B| <= 7 with M odd (sh = 53 for A >= B, 54 for A < B; B = tau's 53-bit significand).
+// Those A are the solutions of A*2^sh = r (mod B), |r| <= 7: enumerate them and test each one.
+typedef unsigned __int128 u128;
+
+uint64_t mod_inverse(uint64_t c, uint64_t m) {         // c^-1 mod m, gcd(c, m) = 1, m > 1
+  __int128 t = 0, nt = 1, r = m, nr = c % m;
+  while (nr != 0) {
+    const __int128 q = r / nr;
+    const __int128 tt = t - q * nt; t = nt; nt = tt;
+    const __int128 rr = r - q * nr; r = nr; nr = rr;
+  }
+  if (t < 0) t += m;
+  return (uint64_t)t;
+}
+
+bool one_step_quotient_ok(uint64_t A, double Bd, double y) {
+  const double a = (double)A;                            // exact: A < 2^53
+  const double q0 = a * y;
+  const double r0 = std::fma(-Bd, q0, a);
+  return std::fma(r0, y, q0) == a / Bd;
+}
+
+// Collects (up to cap) the worst-case significands into out (may be null) and returns whether all pass.
+bool one_step_certified(double tau, std::vector<double> *out = nullptr) {
+  if (!fast_division_ok(tau)) return false;
+  int e;
+  const double m = std::frexp(std::fabs(tau), &e);
+  const uint64_t B = (uint64_t)std::ldexp(m, 53);        // [2^52, 2^53)
+  if (B == (1ull << 52)) return true;                    // power of two: r0 = 0, q1 = q0 exact
+  const double Bd = (double)B, y = 1.0 / Bd;
+  const int v2 = __builtin_ctzll(B);
+  if (v2 > 12) return false;                             // too many solutions to enumerate; use two steps
+  const uint64_t g = 1ull << v2, Bp = B >> v2;           // Bp odd
+  bool ok = true;
+  for (int sh = 53; sh <= 54; ++sh) {
+    const uint64_t c = (uint64_t)((((u128)1) << (sh - v2)) % Bp);
+    const uint64_t cinv = mod_inverse(c, Bp);
+    const uint64_t lo = sh == 53 ? B : (1ull << 52), hi = sh == 53 ? (1ull << 53) : B;
+    for (int r = -7; r <= 7; ++r) {
+      if (r == 0 || (r % (int)g) != 0) continue;
+      const long long rr = r / (long long)g;
+      uint64_t rmod = (uint64_t)(rr >= 0 ? rr : -rr) % Bp;
+      if (rr < 0 && rmod != 0) rmod = Bp - rmod;
+      uint64_t A = (uint64_t)(((u128)rmod * cinv) % Bp);
+      if (A < lo) A += ((lo - A + Bp - 1) / Bp) * Bp;
+      for (; A < hi; A += Bp) {
+        u128 num = ((u128)A) << sh;
+        num = r > 0 ? num - (u128)r : num + (u128)(-r);
+        if (num % B != 0) continue;                      // cannot happen; defensive
+        if (((num / B) & 1) == 0) continue;              // M must be odd to be a midpoint
+        if (out && out->size() < 65536) out->push_back(std::ldexp((double)A, e - 53 + (sh == 53 ? 0 : 0)));
+        if (!one_step_quotient_ok(A, Bd, y)) ok = false;
+      }
+    }
+  }
+  return ok;
+}
+
 bool use_fast_division(const rgs_sim *s) {
   return s->fast_div && fast_division_ok(s->tau_player) && fast_division_ok(s->tau_puck);
 }
@@ -304,10 +368,12 @@ int launch_wave(rgs_sim *s, const StepArgs &args) {
   const long long per_block = (long long)kWavesPerBlock * GPW;
   const long long blocks = (s->B + per_block - 1) / per_block;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * per_block;
-  if (use_fast_division(s))
-    hipLaunchKernelGGL((k_step_wave<N, GW, true>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  if (use_fast_division(s) && s->one_step_ok)
+    hipLaunchKernelGGL((k_step_wave<N, GW, 3>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  else if (use_fast_division(s))
+    hipLaunchKernelGGL((k_step_wave<N, GW, 1>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
   else
-    hipLaunchKernelGGL((k_step_wave<N, GW, false>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+    hipLaunchKernelGGL((k_step_wave<N, GW, 0>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave launch: ") + hipGetErrorString(e));
   return RGS_OK;
@@ -317,7 +383,7 @@ template <int N>
 int launch_wave_noise(rgs_sim *s, const StepArgs &args) {
   const long long blocks = (s->B + kWavesPerBlock - 1) / kWavesPerBlock;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * kWavesPerBlock;
-  hipLaunchKernelGGL((k_step_wave<N, 64, false, true>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
+  hipLaunchKernelGGL((k_step_wave<N, 64, 0, true>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave<noise> launch: ") + hipGetErrorString(e));
   return RGS_OK;
@@ -395,7 +461,9 @@ int launch_hybrid(rgs_sim *s, const StepArgs &args) {
   const long long blocks = (s->B + 63) / 64;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
   const bool fast = use_fast_division(s);
-  if (fast && is_power_of_two(s->tau_player))
+  if (fast && is_power_of_two(s->tau_player) && s->one_step_ok)
+    hipLaunchKernelGGL((k_step_hybrid<N, DIV_POW2_ONESTEP>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  else if (fast && is_power_of_two(s->tau_player))
     hipLaunchKernelGGL((k_step_hybrid<N, DIV_PLAYER_POW2>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
   else if (fast)
     hipLaunchKernelGGL((k_step_hybrid<N, DIV_MARKSTEIN>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
@@ -411,7 +479,9 @@ int launch_hybrid2(rgs_sim *s, const StepArgs &args) {
   const long long blocks = (s->B + 31) / 32;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
   const bool fast = use_fast_division(s);
-  if (fast && is_power_of_two(s->tau_player))
+  if (fast && is_power_of_two(s->tau_player) && s->one_step_ok)
+    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_POW2_ONESTEP>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
+  else if (fast && is_power_of_two(s->tau_player))
     hipLaunchKernelGGL((k_step_hybrid2<N, DIV_PLAYER_POW2>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
   else if (fast)
     hipLaunchKernelGGL((k_step_hybrid2<N, DIV_MARKSTEIN>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
@@ -571,6 +641,7 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
     return fail(RGS_ERR_HIP, m);
   }
   const double zero[4] = {0, 0, 0, 0};
+  s->one_step_ok = one_step_certified(s->tau_player) && one_step_certified(s->tau_puck);
   int rc = do_reset(s, zero, 0);                 // C++ defaults, src/GameSim.cpp:21-25
   if (rc != RGS_OK) { rgs_destroy(s); return rc; }
   *out = s;
@@ -609,6 +680,7 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
     for (long long ar = 0; ar < s->B; ++ar) s->reng[ar] = std::default_random_engine(seed + (int)ar);   // cpp:41
   }
   s->sigma = noise;
+  s->one_step_ok = s->one_step_enabled && one_step_certified(tau_player) && one_step_certified(tau_puck);
   s->dt = dt;
   s->dt_col = dt / kGrid;                        // cpp:28
   s->win = winning_score;
@@ -837,6 +909,8 @@ int rgs_set_variant(rgs_sim *s, int variant) {
 int rgs_set_fast_division(rgs_sim *s, int enable) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_set_fast_division: null handle");
   s->fast_div = enable != 0;
+  s->one_step_enabled = enable >= 2;
+  s->one_step_ok = s->one_step_enabled && one_step_certified(s->tau_player) && one_step_certified(s->tau_puck);
   return RGS_OK;
 }
 
@@ -849,24 +923,39 @@ int rgs_set_sparse_watch(rgs_sim *s, int enable) {
   return RGS_OK;
 }
 
+int rgs_division_info(double tau, int *fast_ok, int *pow2, int *one_step, double *worst_out, int worst_cap,
+                      int *worst_count) {
+  if (fast_ok) *fast_ok = fast_division_ok(tau) ? 1 : 0;
+  if (pow2) *pow2 = is_power_of_two(tau) ? 1 : 0;
+  std::vector<double> w;
+  const bool ok = one_step_certified(tau, &w);
+  if (one_step) *one_step = ok ? 1 : 0;
+  if (worst_count) *worst_count = (int)w.size();
+  if (worst_out)
+    for (int i = 0; i < worst_cap && i < (int)w.size(); ++i) worst_out[i] = w[i];
+  return RGS_OK;
+}
+
 int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double tau, double *fast_host,
-                        double *ieee_host) {
-  if (!a_host || !fast_host || !ieee_host || n < 1) return fail(RGS_ERR_ARG, "rgs_selftest_divtau: bad argument");
+                        double *ieee_host, double *one_host) {
+  if (!a_host || !fast_host || !ieee_host || !one_host || n < 1) return fail(RGS_ERR_ARG, "rgs_selftest_divtau: bad argument");
   if (!fast_division_ok(tau)) return fail(RGS_ERR_UNSUPPORTED, "rgs_selftest_divtau: tau outside the fast-division domain");
   HIP_TRY(hipSetDevice(device_id));
-  double *a = nullptr, *f = nullptr, *q = nullptr;
+  double *a = nullptr, *f = nullptr, *q = nullptr, *o = nullptr;
   const size_t bytes = sizeof(double) * (size_t)n;
   HIP_TRY(hipMalloc(&a, bytes));
   HIP_TRY(hipMalloc(&f, bytes));
   HIP_TRY(hipMalloc(&q, bytes));
+  HIP_TRY(hipMalloc(&o, bytes));
   HIP_TRY(hipMemcpy(a, a_host, bytes, hipMemcpyHostToDevice));
   const int tb = 256;
   hipLaunchKernelGGL(k_selftest_divtau, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, 0, a, (long long)n, tau,
-                     1.0 / tau, f, q);
+                     1.0 / tau, f, q, o);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(fast_host, f, bytes, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ieee_host, q, bytes, hipMemcpyDeviceToHost));
-  hipFree(a); hipFree(f); hipFree(q);
+  HIP_TRY(hipMemcpy(one_host, o, bytes, hipMemcpyDeviceToHost));
+  hipFree(a); hipFree(f); hipFree(q); hipFree(o);
   return RGS_OK;
 }
 

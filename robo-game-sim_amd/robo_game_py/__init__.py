@@ -300,8 +300,11 @@ class BatchedGameSim:
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
 
-    def set_fast_division(self, enable):
-        _lib.check(self._L.rgs_set_fast_division(self._h, int(bool(enable))))
+    def set_fast_division(self, level):
+        """0/False: IEEE division everywhere; 1: reciprocal with two correction steps; 2/True: also the
+        host-certified one-step form (default).  Same results at every level."""
+        level = 2 if level is True else int(level)
+        _lib.check(self._L.rgs_set_fast_division(self._h, level))
 
     def set_sparse_watch(self, enable):
         _lib.check(self._L.rgs_set_sparse_watch(self._h, int(enable)))

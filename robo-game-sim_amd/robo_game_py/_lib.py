@@ -57,7 +57,9 @@ SIGNATURES = {
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
     "rgs_set_fast_division": (C.c_int, [_vp, C.c_int]),
     "rgs_set_sparse_watch": (C.c_int, [_vp, C.c_int]),
-    "rgs_selftest_divtau": (C.c_int, [C.c_int, _dp, C.c_int64, C.c_double, _dp, _dp]),
+    "rgs_division_info": (C.c_int, [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int,
+                                    C.POINTER(C.c_int)]),
+    "rgs_selftest_divtau": (C.c_int, [C.c_int, _dp, C.c_int64, C.c_double, _dp, _dp, _dp]),
     "rgs_selftest_math": (C.c_int, [C.c_int, _dp, _dp, C.c_int64, _dp, _dp]),
 }
 

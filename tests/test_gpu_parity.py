@@ -112,13 +112,26 @@ def test_division_by_tau_rounds_like_ieee(rgp, tau):
     a = np.concatenate([rng.uniform(-12, 12, n // 2), np.exp(rng.uniform(-500, 330, n // 2)) * rng.choice([-1, 1], n // 2),
                         _near_midpoint_dividends(tau, 20000, rng), [0.0, 1.0, -1.0, tau, 3 * tau, 1e-300 * tau]])
     a = np.ascontiguousarray(a)
-    fast = np.empty(a.size)
-    ieee = np.empty(a.size)
+    import ctypes as C
     L = rgp._lib.lib()
-    rgp._lib.check(L.rgs_selftest_divtau(0, rgp._lib.dptr(a), a.size, tau, rgp._lib.dptr(fast), rgp._lib.dptr(ieee)))
+    ok, p2, one_ok, cnt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    worst = np.zeros(65536)
+    rgp._lib.check(L.rgs_division_info(tau, C.byref(ok), C.byref(p2), C.byref(one_ok), rgp._lib.dptr(worst), worst.size,
+                                       C.byref(cnt)))
+    assert ok.value == 1
+    worst = worst[:cnt.value]                                # quotients within 2^-51 ulp of a midpoint
+    a = np.ascontiguousarray(np.concatenate([a, worst, -worst, worst * 2.0 ** 37, worst * 2.0 ** -61]))
+    fast, ieee, one = np.empty(a.size), np.empty(a.size), np.empty(a.size)
+    rgp._lib.check(L.rgs_selftest_divtau(0, rgp._lib.dptr(a), a.size, tau, rgp._lib.dptr(fast), rgp._lib.dptr(ieee),
+                                         rgp._lib.dptr(one)))
     host = a / tau
     assert np.array_equal(ieee.view(np.uint64), host.view(np.uint64))
     assert np.array_equal(fast, host), "%d of %d quotients differ" % (int((fast != host).sum()), a.size)
+    if one_ok.value:                                         # host-certified: one correction step suffices
+        assert cnt.value > 0 or p2.value
+        assert np.array_equal(one, host), "one-step: %d of %d quotients differ" % (int((one != host).sum()), a.size)
+    else:                                                    # not certified => some worst case really fails
+        print("tau=%r not certified for one step (%d worst cases)" % (tau, cnt.value))
 
 
 def test_fast_and_ieee_division_builds_agree(rgp, oracle):
@@ -128,13 +141,14 @@ def test_fast_and_ieee_division_builds_agree(rgp, oracle):
     x0, amp, ph = w.c2_inputs(B, n, seed=21)
     table = w.circle_controls(amp * 2.5, ph, w.step_times(K, 0.05))
     res = []
-    for fast in (True, False):
+    for fast in (2, 1, 0):
         sim = rgp.BatchedGameSim(B, n)
         sim.set_fast_division(fast)
         sim.reset(0.05, 1000, x0)
         res.append(sim.run_table(table))
         sim.close()
-    assert_same(res[0], res[1], "fast vs ieee division")
+    assert_same(res[0], res[1], "one-step vs two-step division")
+    assert_same(res[0], res[2], "fast vs ieee division")
     ref = oracle.batch_run(n, x0, table, K, dt=0.05, winning_score=1000, n_threads=8)
     assert_same(res[0], ref["state"], "fast division vs oracle")
 
