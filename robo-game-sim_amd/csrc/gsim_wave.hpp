@@ -81,9 +81,13 @@ __device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuc
 // UP, DOWN, RIGHT, LEFT and the other discs in entity order; strict '<' keeps the first found.
 // The pair test fl(sqrt(s)) <= R (cpp:471) is evaluated as s <= le, le = the largest double whose
 // correctly rounded square root is <= R (host-computed, StepArgs::le_*): same truth value, no sqrt.
+// partners: discs to run the pair test against (bit o).  The first scan of a step may pass the lane
+// pass' disc mask -- a pair can only overlap at a column of the untouched grid if the (superset) watch
+// fired for BOTH of its discs; every later scan passes all ones.
 template <int N>
 __device__ __forceinline__ void column_candidate(const StepArgs &p, const double *G, int g, int id, double t0,
-                                                 double dt_col, double &best_t, int &best_j, int &best_kind) {
+                                                 double dt_col, unsigned partners, double &best_t, int &best_j,
+                                                 int &best_kind) {
   using L = WaveLayout<N>;
   const double *ck = G + g * L::CS;
   const double *cm = G + (g - 1) * L::CS;
@@ -121,7 +125,7 @@ __device__ __forceinline__ void column_candidate(const StepArgs &p, const double
   }
 #pragma unroll
   for (int o = 0; o < L::E; ++o) {                           // cpp:466-498
-    if (o == id) continue;
+    if (o == id || !((partners >> o) & 1u)) continue;
     const double rad_o = disc_radius<N>(o);
     const double ddx = kpx - ck[4 * o], ddy = kpy - ck[4 * o + 1];
     const double le = (id == L::PK || o == L::PK) ? p.le_pk : p.le_pp;
@@ -146,15 +150,15 @@ __device__ __forceinline__ void column_candidate(const StepArgs &p, const double
 // candidate satisfies t_col - t_ < dt_.  Group-uniform result.
 template <int N, int GW>
 __device__ __forceinline__ bool scan_disc(const StepArgs &p, const double *G, int id, int base, double t0, double dt,
-                                          double dt_col, int lg, int gbase, double &out_t, int &out_j,
-                                          int &out_kind) {
+                                          double dt_col, int lg, int gbase, unsigned partners, double &out_t,
+                                          int &out_j, int &out_kind) {
   for (int g0 = base; g0 <= kGrid; g0 += GW) {
     const int g = g0 + lg;
     bool hit = false;
     double bt = 1.0e9;
     int bj = -1, bk = -1;
     if (g <= kGrid) {
-      column_candidate<N>(p, G, g, id, t0, dt_col, bt, bj, bk);
+      column_candidate<N>(p, G, g, id, t0, dt_col, partners, bt, bj, bk);
       hit = (bt - t0 < dt);                                  // cpp:501
     }
     const unsigned long long m = group_ballot<GW>(hit, gbase);
@@ -290,7 +294,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
 #pragma unroll
   for (int id = 0; id < E; ++id) {                           // first pass: checks = all discs, cpp:145
     double tt; int jj, kk;
-    if (((discmask >> id) & 1u) && scan_disc<N, GW>(p, G, id, scan_from, t0, dt, dt_col, lg, gbase, tt, jj, kk))
+    if (((discmask >> id) & 1u) && scan_disc<N, GW>(p, G, id, scan_from, t0, dt, dt_col, lg, gbase, discmask & 0xFFFFu, tt, jj, kk))
       ev.put(id, tt, jj, kk, seq++);
   }
   counter = 1;
@@ -435,8 +439,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     ev.purge(ci, cj);                                        // cpp:347-352
     {                                                        // re-scan i_ then j_, cpp:355-357 -> 147
       double tt; int jj, kk;
-      if (scan_disc<N, GW>(p, G, ci, base, t0, dt, dt_col, lg, gbase, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
-      if (cj >= 0 && scan_disc<N, GW>(p, G, cj, base, t0, dt, dt_col, lg, gbase, tt, jj, kk))
+      if (scan_disc<N, GW>(p, G, ci, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
+      if (cj >= 0 && scan_disc<N, GW>(p, G, cj, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk))
         ev.put(cj, tt, jj, kk, seq++);
     }
   }

@@ -128,13 +128,18 @@ __global__ __launch_bounds__(64) void k_step_hybrid2(StepArgs p) {
   const int ax = lane & 1;
   const bool mine = a < p.B;
   double *G = lds + grp * WaveLayout<N>::DOUBLES;
+  unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
+  if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < p.n_steps; ++k) {
     const double *ctl = p.ctl + (long long)k * p.ctl_stride;
     unsigned discmask = 0u;
+    unsigned long long t0 = 0, t1 = 0;
+    if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
     const bool slow = mine && lane_step_split<N, MODE>(p, ctl, a, ax, discmask);
     unsigned long long m = __ballot(slow) & 0x5555555555555555ull;      // one bit per arena (its x lane)
     if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
     __syncthreads();
+    if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
     while (m != 0ull) {
       int bit = -1;
       unsigned long long mm = m;
@@ -145,10 +150,18 @@ __global__ __launch_bounds__(64) void k_step_hybrid2(StepArgs p) {
         mm &= mm - 1ull;
       }
       m = mm;
+      n_rounds++;
       const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
       if (bit >= 0) arena_step_group<N, GW, FAST>(p, ctl, a0 + (bit >> 1), G, lg, lane - lg, dm);
     }
     __syncthreads();
+    if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
+  }
+  if (GSIM_STAMPS && p.stamps && lane == 0) {
+    atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
+    atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
+    atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
+    atomicAdd(&p.stamp_out[STAMP_TOTAL], __builtin_amdgcn_s_memtime() - t_begin);
   }
 }
 
