@@ -63,7 +63,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
 template <int N>
 struct HybridGroups {
   static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16 : 32;
-  static constexpr int GPW = 64 / GW;
+  // Arenas re-run side by side = LDS grids per block.  The kernels' register footprint allows 4 waves
+  // per CU, so a block may use at most 160 KB / 4 = 40 KB of LDS or residency drops below one wave
+  // per SIMD (measured at 7v7: two 24.9 KB grids -> 3 blocks per CU, 1.48e8; one grid -> 1.79e8).
+  static constexpr int GRID_BYTES = 8 * WaveLayout<N>::DOUBLES;
+  static constexpr int FIT = (40 * 1024) / GRID_BYTES;
+  static constexpr int GPW = (64 / GW) < FIT ? (64 / GW) : (FIT < 1 ? 1 : FIT);
 };
 
 template <int N, int MODE>
