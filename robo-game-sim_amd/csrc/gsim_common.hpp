@@ -16,6 +16,9 @@
 #ifndef GSIM_WIDE_GROUPS
 #define GSIM_WIDE_GROUPS 0
 #endif
+#ifndef GSIM_H2_WAVES
+#define GSIM_H2_WAVES 1
+#endif
 #ifndef GSIM_STAMPS
 #define GSIM_STAMPS 0
 #endif

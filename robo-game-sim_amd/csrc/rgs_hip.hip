@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
 
 // Hybrid with two lanes per arena (gsim_lane.hpp, lane_step_split): 32 arenas per wave.
 template <int N, int MODE>
-__global__ __launch_bounds__(64) void k_step_hybrid2(StepArgs p) {
+__global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
