@@ -19,6 +19,12 @@
 #ifndef GSIM_H2_WAVES
 #define GSIM_H2_WAVES 1
 #endif
+#ifndef GSIM_H1_WAVES
+#define GSIM_H1_WAVES 1
+#endif
+#ifndef GSIM_CHAIN_BATCH
+#define GSIM_CHAIN_BATCH 0
+#endif
 #ifndef GSIM_STAMPS
 #define GSIM_STAMPS 0
 #endif

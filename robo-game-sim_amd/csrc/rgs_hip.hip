@@ -72,7 +72,7 @@ struct HybridGroups {
 };
 
 template <int N, int MODE>
-__global__ __launch_bounds__(64) void k_step_hybrid(StepArgs p) {
+__global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
