@@ -233,6 +233,21 @@ def main():
                 "kernel_ms_per_launch": round(launch_s * 1e3, 4), "launches": launches,
                 "bytes_per_arena_step": algorithmic_bytes_per_arena_step(n),
                 "note": "path is FP64-VALU/latency bound, not HBM bound; see fp64_model and DESIGN.md"}
+    # VALU issue view (the bound that actually binds): wave-instructions per wave-step from the committed PMC
+    # pass (profiles/r01/hybrid_pmc.json, SQ_INSTS_VALU) x measured wave-steps/s, against one fp64 wave64
+    # instruction per 4 cycles per SIMD-32 (1024 SIMDs x 2.4 GHz / 4).
+    valu_issue = None
+    try:
+        if n == 2 and args.variant != 1 and args.config == "c2":
+            per_wave_step = pmc["_per_arena_step"]["valu_insts_per_wave_step"]
+            wave_steps_per_s = (B / 64.0) * K / (kernel_ms * 1e-3)
+            peak = 1024 * 2.4e9 / 4.0
+            valu_issue = {"achieved": round(per_wave_step * wave_steps_per_s / 1e9, 2), "peak": round(peak / 1e9, 1),
+                          "unit": "G wave-instr/s", "frac": round(per_wave_step * wave_steps_per_s / peak, 4),
+                          "valu_wave_instr_per_wave_step": round(per_wave_step, 1),
+                          "source": "SQ_INSTS_VALU from profiles/r01/hybrid_pmc.json (not collected live)"}
+    except Exception:
+        valu_issue = None
     model_tflops = model_flops_per_arena_step(n) * B * K / (kernel_ms * 1e-3) / 1e12
     fp64_model = {"flops_per_arena_step": model_flops_per_arena_step(n), "achieved": round(model_tflops, 4),
                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(model_tflops / FP64_VECTOR_PEAK_TFLOPS, 5)}
@@ -276,7 +291,7 @@ def main():
                                    % (args.config.upper(), B, n, n, DT, WIN),
                        "arenas_per_gpu": B, "n_per_team": n, "steps_per_launch": args.steps_per_launch,
                        "variant": args.variant, "parallelism": "arena-sharded x%d, end-of-run all-gather" % world},
-            "roofline": roofline, "fp64_model": fp64_model, "cpu_baseline": cpu, "parity": parity, "host_streamed": streamed,
+            "roofline": roofline, "fp64_model": fp64_model, "valu_issue": valu_issue, "cpu_baseline": cpu, "parity": parity, "host_streamed": streamed,
             "events": counters,
         }
         print(json.dumps(out), flush=True)
