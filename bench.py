@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--force-device", type=int, default=-1, help="rehearsal only: every rank uses this GPU")
     ap.add_argument("--watch-every", type=int, default=-1, help="diagnostic: pair-watch interval (0 dense, 2, 5, 10)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: in-kernel phase stamps (slightly perturbs timing)")
+    ap.add_argument("--jam", action="store_true", help="diagnostic: drive every player towards the arena centre "
+                    "(sustained contact, many 49-event steps): the hybrid's worst case")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
     args = ap.parse_args()
     preset = {"c2": (2, 65536, 0.01, 1000000), "c3": (7, 65536, 0.01, 1000000), "c4": (2, 131072, 0.05, 4),
@@ -132,6 +134,15 @@ def main():
         table[k0:k0 + CH, :, 0, :] = amp_d[None] * torch.cos(arg)
         table[k0:k0 + CH, :, 1, :] = amp_d[None] * torch.sin(arg)
     del arg
+    if args.jam:                                               # constant pull to the centre, strength from amp
+        import robo_game_py as _r
+        s0 = _r.BatchedGameSim(B, n, device=local_rank)
+        st0 = torch.from_numpy(s0.reset(DT, WIN, np.ascontiguousarray(x0))).to(dev)
+        s0.close()
+        for e in range(P):
+            d = -st0[6 + 4 * e:8 + 4 * e]                    # spawn position -> centre
+            d = d / torch.clamp(torch.sqrt((d * d).sum(0)), min=1e-9)
+            table[:, e, :, :] = (amp_d[e] * d)[None]
     torch.cuda.synchronize()
 
     sim = rgp.BatchedGameSim(B, n, device=local_rank)

@@ -35,7 +35,9 @@ enum {
   RGS_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
 };
 
-/* Stepper variants (rgs_set_variant).  All give bit-identical results. */
+/* Stepper variants (rgs_set_variant).  All give bit-identical results.  AUTO picks the hybrid that
+ * suits n and, looking at the event counters every >= 64 steps, falls back to the wave-per-arena
+ * kernel while most arenas are in contact. */
 enum {
   RGS_VARIANT_AUTO = 0,
   RGS_VARIANT_WAVE = 1,      /* one wavefront owns one arena, grid in LDS */
@@ -123,7 +125,8 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * out[0] events resolved, [1] steps ended by the 50-iteration cap (include/GameSim.h:7),
  * [2] base index past the grid (reference: out-of-bounds write; clamped here), [3] puck events
  * skipped after a goal (src/GameSim.cpp:230-231), [4] arena-steps whose first scan found an
- * event, [5] arena-steps the hybrid's lane pass handed to the wave pass, [6..7] reserved. */
+ * event, [5] arena-steps the hybrid's lane pass handed to the wave pass, [6] reserved, [7] 1 if
+ * RGS_VARIANT_AUTO currently prefers the wave-per-arena kernel (sustained-contact regime), else 0. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
 /* Diagnostic in-kernel stamps (s_memtime) of the one-lane hybrid kernel; only in a library built with

@@ -270,6 +270,10 @@ struct rgs_sim {
   bool sparse_watch = true;        // cleared by rgs_set_sparse_watch(0)
   bool stamps = false;             // rgs_get_stamps(enable)
   bool one_step_ok = false;        // both taus pass one_step_certified (set by reset)
+  // AUTO variant: contact regime estimate (see launch_steps)
+  bool auto_wave = false;          // currently preferring the wave-per-arena kernel
+  long long window_steps = 0;      // steps launched since the last look at the counters
+  unsigned long long seen_busy = 0;  // flagged + event_steps at that look
   bool one_step_enabled = true;    // rgs_set_fast_division(2) = allow, (1) = two steps only
   // noise > 0: the reference's generator per arena, src/GameSim.cpp:3,41 -- the engine is
   // re-seeded by reset(), the distribution (with its cached second draw) deliberately is not.
@@ -551,7 +555,28 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   }
   // AUTO: measured on MI355X (profiles/r01): one lane per arena wins up to 3v3; from 4v4 on its
   // register footprint spills and the two-lanes-per-arena form is faster (4v4 +48 %, 7v7 +11 %).
-  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->n >= 4 ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID);
+  // Both hybrids assume that flagged arenas are the exception.  In sustained contact (most arenas
+  // flagged every step, many 49-event steps) the plain wave-per-arena kernel, with four waves per SIMD
+  // to hide its latency, is faster (measured crossover near 10 % flagged: 76 % flagged 3.4e7 vs 1.9e7).
+  // So every >= 64 launched steps AUTO looks at the counters of the finished launches and switches
+  // with hysteresis (> 15 % busy arena-steps -> wave kernel, < 8 % -> hybrid).  Results are identical
+  // either way; only this host-side choice depends on the history.
+  if (s->variant == RGS_VARIANT_AUTO && s->window_steps >= 64) {
+    unsigned long long c[CNT_N];
+    HIP_TRY(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const unsigned long long busy = s->auto_wave ? c[CNT_EVENT_STEPS] : c[CNT_FLAGGED];
+    const unsigned long long both = c[CNT_EVENT_STEPS] + c[CNT_FLAGGED];   // monotone across switches
+    const double ratio = (double)(both - s->seen_busy) / ((double)s->window_steps * (double)s->B);
+    (void)busy;
+    if (!s->auto_wave && ratio > 0.15) s->auto_wave = true;
+    else if (s->auto_wave && ratio < 0.08) s->auto_wave = false;
+    s->seen_busy = both;
+    s->window_steps = 0;
+  }
+  if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
+  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant
+                      : (s->auto_wave ? RGS_VARIANT_WAVE : (s->n >= 4 ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID));
   if (variant == RGS_VARIANT_HYBRID2) {
     switch (s->n) {
       case 1: return launch_hybrid2<1>(s, a);
@@ -698,6 +723,7 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
     for (long long ar = 0; ar < s->B; ++ar) s->reng[ar] = std::default_random_engine(seed + (int)ar);   // cpp:41
   }
   s->sigma = noise;
+  s->auto_wave = false; s->window_steps = 0; s->seen_busy = 0;
   s->one_step_ok = s->one_step_enabled && one_step_certified(tau_player) && one_step_certified(tau_puck);
   s->dt = dt;
   s->dt_col = dt / kGrid;                        // cpp:28
@@ -902,6 +928,7 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out8, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  out8[7] = s->auto_wave ? 1 : 0;
   return RGS_OK;
 }
 

@@ -288,7 +288,9 @@ class BatchedGameSim:
         out = (C.c_int64 * 8)()
         _lib.check(self._L.rgs_get_counters(self._h, out))
         names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps", "flagged"]
-        return dict(zip(names, list(out)[:6]))
+        d = dict(zip(names, list(out)[:6]))
+        d["auto_prefers_wave"] = int(out[7])
+        return d
 
     def stamps(self, enable=True):
         """Diagnostic: enable/disable in-kernel phase stamps and return the totals so far."""

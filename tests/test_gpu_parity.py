@@ -418,6 +418,36 @@ def test_noise_batched_with_many_events(rgp, oracle, n):
     sim.close()
 
 
+def test_auto_variant_switches_in_sustained_contact(rgp, oracle):
+    """AUTO watches the event counters between launches: a jammed arena set (everybody pushed to the
+    centre) makes it prefer the wave-per-arena kernel, calm play brings the hybrid back; the states are
+    the same bits as the oracle's throughout."""
+    n, B, dt = 2, 512, 0.05
+    x0 = np.zeros((4, B))
+    sim = rgp.BatchedGameSim(B, n)
+    state = sim.reset(dt, 1000, x0)
+    pull = np.zeros((4, 2, B))
+    for e in range(4):
+        d = -state[6 + 4 * e:8 + 4 * e]
+        pull[e] = 4.0 * d / np.sqrt((d * d).sum(0))
+    table = np.ascontiguousarray(np.broadcast_to(pull, (70, 4, 2, B)))
+    prefers = []
+    for _ in range(4):                                        # 4 launches of 70 steps: jam builds up
+        state = sim.run_table(table, chunk_steps=70)
+        prefers.append(sim.counters()["auto_prefers_wave"])
+    assert prefers[-1] == 1, prefers
+    ref = oracle.batch_run(n, x0, np.concatenate([table] * 4), 280, dt=dt, winning_score=1000, n_threads=8)
+    assert_same(state, ref["state"], "jam")
+    calm = np.zeros((10, 4, 2, B))
+    spread = np.array([[-3.0, 1.5], [-3.0, -1.5], [3.0, 1.5], [3.0, -1.5]])
+    for k in range(60):                                       # closed loop: walk everybody back out, then rest
+        pos = state[6:22].reshape(4, 4, B)[:, :2]
+        calm[:] = np.clip(1.0 * (spread[:, :, None] - pos), -1.5, 1.5)[None]
+        state = sim.run_table(calm, chunk_steps=10)
+    assert sim.counters()["auto_prefers_wave"] == 0
+    sim.close()
+
+
 def test_noise_is_limited_not_faked(rgp):
     sim = rgp.BatchedGameSim(5000, 2)
     with pytest.raises(rgp.RgsError):
