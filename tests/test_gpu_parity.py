@@ -418,6 +418,50 @@ def test_noise_batched_with_many_events(rgp, oracle, n):
     sim.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_parameter_fuzz(rgp, oracle, seed):
+    """Seeded random physics / timing parameters, team sizes and control styles, every variant, against
+    the oracle: final state, damage, event counters.  Includes taus that are not powers of two (two-step
+    or one-step reciprocal division), dt_col/tau > 0.1 (dense watch) and tiny winning scores (games that
+    end mid-run and freeze)."""
+    from robo_game_py import workloads as w
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 2, 3, 4, 5, 6, 7]))
+    B, K = 192, int(rng.integers(60, 160))
+    dt = float(rng.choice([0.002, 0.01, 0.02, 0.05, 0.1]))
+    phys = dict(tau_puck=float(rng.choice([0.1, 0.1, 0.05, 0.3, 1.0, 0.013])),
+                tau_player=float(rng.choice([0.5, 0.5, 0.25, 0.4, 0.07, 1.0 / 3.0])),
+                player_mass=float(rng.uniform(0.3, 3.0)), puck_mass=float(rng.uniform(0.1, 2.0)))
+    win = int(rng.choice([1, 2, 3, 1000]))
+    x0, amp, ph = w.c2_inputs(B, n, seed=seed)
+    x0[2:] *= rng.uniform(0.5, 4.0)
+    style = seed % 3
+    if style == 0:
+        table = w.random_hold_controls(2 * n, B, K, float(rng.uniform(2, 10)), hold=int(rng.integers(3, 30)), seed=seed)
+    elif style == 1:
+        table = w.circle_controls(amp * rng.uniform(0.5, 3.0), ph, w.step_times(K, dt))
+    else:                                                     # everybody towards the puck's start: pile-ups
+        s0 = oracle.OracleGameSim(n).reset(dt, win, np.zeros(4))
+        table = np.zeros((K, 2 * n, 2, B))
+        for e in range(2 * n):
+            d = x0[:2] - s0[6 + 4 * e:8 + 4 * e, None]
+            table[:, e] = (float(rng.uniform(2, 6)) * d / np.maximum(1e-9, np.sqrt((d * d).sum(0))))[None]
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=win, n_threads=8, want_damage=True, **phys)
+    for variant in (1, 2, 3):
+        sim = rgp.BatchedGameSim(B, n)
+        sim.set_variant(variant)
+        sim.reset(dt, win, x0, 0.0, False, "", 0, phys["tau_puck"], phys["tau_player"], phys["player_mass"], phys["puck_mass"])
+        got = sim.run_table(table, chunk_steps=int(rng.integers(1, K + 1)))
+        what = "fuzz seed %d n=%d dt=%g variant %d %r" % (seed, n, dt, variant, phys)
+        assert_same(got, ref["state"], what)
+        assert_same(sim.damage().reshape(4 * n * n, B), ref["damage"], what + " damage")
+        c = sim.counters()
+        for k in ("resolved", "cap_hits", "skipped_after_goal", "base_overflow"):
+            assert c[k] == ref["stats"][k], (what, k, c, ref["stats"])
+        assert_same(sim.undecided(), (ref["state"][0] < win) & (ref["state"][1] < win), what + " undecided")
+        sim.close()
+
+
 def test_auto_variant_switches_in_sustained_contact(rgp, oracle):
     """AUTO watches the event counters between launches: a jammed arena set (everybody pushed to the
     centre) makes it prefer the wave-per-arena kernel, calm play brings the hybrid back; the states are
