@@ -78,6 +78,7 @@ struct StepArgs {
   const double *tape;
   int tape_len;
   int *consumed;                     // [B] draws used by this step (> tape_len: tape too short, redo)
+  double *vgrid;                     // two-lane hybrid, n >= 4: velocity rows of the grids (GridView<N, true>)
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]

@@ -74,6 +74,42 @@ struct WaveLayout {
   static constexpr int DOUBLES = U_OFF + 2 * E + 1; // per arena (odd => groups shift banks)
 };
 
+// The 51-column grid of one arena.  SPLITV = false: positions and velocities side by side in LDS
+// (WaveLayout).  SPLITV = true (two-lane hybrid from 6v6 up): LDS keeps the positions only -- every
+// scan reads them, for every disc, at every column -- and the velocity rows, which are read only when a
+// test fires (back-tracking, cpp:385-392, 482-494) and at the start of a carry-out (cpp:255, 309), live
+// in a per-block global scratch that stays in L2.  Half the LDS per arena = twice the arenas re-run
+// side by side under the same 40 KB-per-block budget.
+template <int N, bool SPLITV>
+struct GridView {
+  static constexpr int E = 2 * N + 1;
+  static constexpr int CS = SPLITV ? 2 * E + 1 : 4 * E + 1;          // odd: lane<->column reads hit distinct banks
+  static constexpr int U_OFF = kCols * CS;
+  static constexpr int LDS_DOUBLES = U_OFF + 2 * E + 1;
+  static constexpr int GV_DOUBLES = SPLITV ? kCols * 2 * E : 0;
+  double *lds;
+  double *gv;
+  __device__ __forceinline__ double &pos(int g, int e, int ax) const { return lds[g * CS + (SPLITV ? 2 : 4) * e + ax]; }
+  __device__ __forceinline__ double &vel(int g, int e, int ax) const {
+    if (SPLITV) return gv[g * (2 * E) + 2 * e + ax];
+    return lds[g * CS + 4 * e + 2 + ax];
+  }
+  __device__ __forceinline__ double &ctl(int e, int ax) const { return lds[U_OFF + 2 * e + ax]; }
+};
+
+// wave_sync that also orders this wave's global-memory traffic (the split grid's velocity rows): a
+// workgroup-scope fence waits for the outstanding stores; all waves of a workgroup share the CU's L1.
+template <bool SPLITV>
+__device__ __forceinline__ void grid_sync() {
+  if (SPLITV) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else {
+    wave_sync();
+  }
+}
+
 template <int N>
 __device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuck : kRPlayer; }
 
@@ -84,42 +120,41 @@ __device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuc
 // partners: discs to run the pair test against (bit o).  The first scan of a step may pass the lane
 // pass' disc mask -- a pair can only overlap at a column of the untouched grid if the (superset) watch
 // fired for BOTH of its discs; every later scan passes all ones.
-template <int N>
-__device__ __forceinline__ void column_candidate(const StepArgs &p, const double *G, int g, int id, double t0,
+template <int N, bool SPLITV>
+__device__ __forceinline__ void column_candidate(const StepArgs &p, const GridView<N, SPLITV> &G, int g, int id, double t0,
                                                  double dt_col, unsigned partners, double &best_t, int &best_j,
                                                  int &best_kind) {
   using L = WaveLayout<N>;
-  const double *ck = G + g * L::CS;
-  const double *cm = G + (g - 1) * L::CS;
+  const int gm = g - 1;
   const double rad = disc_radius<N>(id);
-  const double kpx = ck[4 * id], kpy = ck[4 * id + 1];
+  const double kpx = G.pos(g, id, 0), kpy = G.pos(g, id, 1);
   const double t_m = t0 + dt_col * (double)(g - 1);          // T row, cpp:201 (g-1 = 0 gives t_)
   best_t = 1.0e9; best_j = -1; best_kind = -1;               // Collision(), Collision.h:9
   if (kpy + rad >= kY / 2.0) {                               // cpp:374-394
-    const double mvy = cm[4 * id + 3];
+    const double mvy = G.vel(gm, id, 1);
     if (mvy > 0) {
-      const double tc = t_m + max0(div_ieee(kY / 2.0 - rad - cm[4 * id + 1], mvy));
+      const double tc = t_m + max0(div_ieee(kY / 2.0 - rad - G.pos(gm, id, 1), mvy));
       if (tc < best_t) { best_t = tc; best_j = -1; best_kind = UP; }
     }
   }
   if (kpy - rad <= -kY / 2.0) {                              // cpp:397-417
-    const double mvy = cm[4 * id + 3];
+    const double mvy = G.vel(gm, id, 1);
     if (mvy < 0) {
-      const double tc = t_m + max0(div_ieee(-kY / 2.0 + rad - cm[4 * id + 1], mvy));
+      const double tc = t_m + max0(div_ieee(-kY / 2.0 + rad - G.pos(gm, id, 1), mvy));
       if (tc < best_t) { best_t = tc; best_j = -1; best_kind = DOWN; }
     }
   }
   if (kpx + rad >= kX / 2.0) {                               // cpp:420-440
-    const double mvx = cm[4 * id + 2];
+    const double mvx = G.vel(gm, id, 0);
     if (mvx > 0) {
-      const double tc = t_m + max0(div_ieee(kX / 2.0 - rad - cm[4 * id], mvx));
+      const double tc = t_m + max0(div_ieee(kX / 2.0 - rad - G.pos(gm, id, 0), mvx));
       if (tc < best_t) { best_t = tc; best_j = -1; best_kind = RIGHT; }
     }
   }
   if (kpx - rad <= -kX / 2.0) {                              // cpp:443-463
-    const double mvx = cm[4 * id + 2];
+    const double mvx = G.vel(gm, id, 0);
     if (mvx < 0) {
-      const double tc = t_m + max0(div_ieee(-kX / 2.0 + rad - cm[4 * id], mvx));
+      const double tc = t_m + max0(div_ieee(-kX / 2.0 + rad - G.pos(gm, id, 0), mvx));
       if (tc < best_t) { best_t = tc; best_j = -1; best_kind = LEFT; }
     }
   }
@@ -127,11 +162,11 @@ __device__ __forceinline__ void column_candidate(const StepArgs &p, const double
   for (int o = 0; o < L::E; ++o) {                           // cpp:466-498
     if (o == id || !((partners >> o) & 1u)) continue;
     const double rad_o = disc_radius<N>(o);
-    const double ddx = kpx - ck[4 * o], ddy = kpy - ck[4 * o + 1];
+    const double ddx = kpx - G.pos(g, o, 0), ddy = kpy - G.pos(g, o, 1);
     const double le = (id == L::PK || o == L::PK) ? p.le_pk : p.le_pp;
     if (ddx * ddx + ddy * ddy <= le) {                       // cpp:471
-      const double dpx = cm[4 * o] - cm[4 * id], dpy = cm[4 * o + 1] - cm[4 * id + 1];         // cpp:484
-      const double dvx = cm[4 * o + 2] - cm[4 * id + 2], dvy = cm[4 * o + 3] - cm[4 * id + 3]; // cpp:485
+      const double dpx = G.pos(gm, o, 0) - G.pos(gm, id, 0), dpy = G.pos(gm, o, 1) - G.pos(gm, id, 1);   // cpp:484
+      const double dvx = G.vel(gm, o, 0) - G.vel(gm, id, 0), dvy = G.vel(gm, o, 1) - G.vel(gm, id, 1);   // cpp:485
       const double sigma = rad + rad_o;
       const double dpdv = dpx * dvx + dpy * dvy;
       const double dvdv = dvx * dvx + dvy * dvy;
@@ -148,8 +183,8 @@ __device__ __forceinline__ void column_candidate(const StepArgs &p, const double
 
 // insertCollisions' inner loop for one disc (cpp:365-506): first column >= base whose best
 // candidate satisfies t_col - t_ < dt_.  Group-uniform result.
-template <int N, int GW>
-__device__ __forceinline__ bool scan_disc(const StepArgs &p, const double *G, int id, int base, double t0, double dt,
+template <int N, int GW, bool SPLITV>
+__device__ __forceinline__ bool scan_disc(const StepArgs &p, const GridView<N, SPLITV> &G, int id, int base, double t0, double dt,
                                           double dt_col, int lg, int gbase, unsigned partners, double &out_t,
                                           int &out_j, int &out_kind) {
   for (int g0 = base; g0 <= kGrid; g0 += GW) {
@@ -158,7 +193,7 @@ __device__ __forceinline__ bool scan_disc(const StepArgs &p, const double *G, in
     double bt = 1.0e9;
     int bj = -1, bk = -1;
     if (g <= kGrid) {
-      column_candidate<N>(p, G, g, id, t0, dt_col, partners, bt, bj, bk);
+      column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, partners, bt, bj, bk);
       hit = (bt - t0 < dt);                                  // cpp:501
     }
     const unsigned long long m = group_ballot<GW>(hit, gbase);
@@ -236,18 +271,17 @@ struct EventSlots {
 // column (cpp:255-256, 287-288, 294-295 / 309, 331, 338); the puck draws nothing.  `cur` is that
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
-template <int N, int GW, int FAST, bool NOISE = false>
-__device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a, double *G,
-                                 int lg, int gbase, unsigned discmask) {
+template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false>
+__device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
+                                 const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
-  constexpr int E = L::E, PK = L::PK, CS = L::CS;
+  constexpr int E = L::E, PK = L::PK;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
   const long long B = p.B;
   double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
   if (!(TAS < p.win && TBS < p.win)) return;                 // undecided(), cpp:57-60,121
   const double t0 = p.tcur[a];
   const double dt = p.dt, dt_col = p.dt_col;
-  double *U = G + L::U_OFF;
   const double *tape = NOISE ? p.tape + a * (long long)p.tape_len : nullptr;
   const int tape_last = NOISE ? p.tape_len - 8 : 0;         // last legal start of an 8-draw record
   int cur = 0;                                              // draws consumed so far (group-uniform)
@@ -264,9 +298,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     x.v = p.state[(long long)(row + 2 + ax) * B + a];
     double u = 0.0, coef = 0.2, tau = p.tau_puck, inv = p.inv_tau_puck;   // cpp:188: puck input is (0, 0)
     if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; inv = p.inv_tau_player; }
-    U[2 * e + ax] = u;
-    G[4 * e + ax] = x.p;
-    G[4 * e + 2 + ax] = x.v;
+    G.ctl(e, ax) = u;
+    G.pos(0, e, ax) = x.p;
+    G.vel(0, e, ax) = x.v;
     const bool fast = FAST != 0 && fast_division_safe(u, x.v);
     const double sg = e != PK ? p.sigma : 0.0;
     for (int i = 1; i <= kGrid; ++i) {
@@ -275,12 +309,12 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
         x = rk4_axis_noise(x, u, coef, tau, dt_col, sg, tape + (c0 < tape_last ? c0 : tape_last) + ax);
       } else
       x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);
-      G[i * CS + 4 * e + ax] = x.p;
-      G[i * CS + 4 * e + 2 + ax] = x.v;
+      G.pos(i, e, ax) = x.p;
+      G.vel(i, e, ax) = x.v;
     }
   }
   if (NOISE) cur = 8 * kGrid * L::P;
-  wave_sync();
+  grid_sync<SPLITV>();
   if (stamp) ts1 = __builtin_amdgcn_s_memtime();
 
   // ---- event loop, cpp:136-150 ----
@@ -294,7 +328,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
 #pragma unroll
   for (int id = 0; id < E; ++id) {                           // first pass: checks = all discs, cpp:145
     double tt; int jj, kk;
-    if (((discmask >> id) & 1u) && scan_disc<N, GW>(p, G, id, scan_from, t0, dt, dt_col, lg, gbase, discmask & 0xFFFFu, tt, jj, kk))
+    if (((discmask >> id) & 1u) && scan_disc<N, GW, SPLITV>(p, G, id, scan_from, t0, dt, dt_col, lg, gbase, discmask & 0xFFFFu, tt, jj, kk))
       ev.put(id, tt, jj, kk, seq++);
   }
   counter = 1;
@@ -321,12 +355,12 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       const bool first = lg < 2;
       const int d = (is_pair && !first) ? cj : ci, ax = lg & 1;
       const double r_own = disc_radius<N>(d);
-      const double u = U[2 * d + ax];
+      const double u = G.ctl(d, ax);
       const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
       const double inv = d == PK ? p.inv_tau_puck : p.inv_tau_player;
       Chain x;
-      x.p = G[(base - 1) * CS + 4 * d + ax];
-      x.v = G[(base - 1) * CS + 4 * d + 2 + ax];
+      x.p = G.pos(base - 1, d, ax);
+      x.v = G.vel(base - 1, d, ax);
       bool fast = FAST != 0 && fast_division_safe(u, x.v);
       // noise bookkeeping: np players among the event's discs draw; this lane's disc is the slot-th of them
       const int np = NOISE ? ((ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0)) : 0;
@@ -420,8 +454,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           }
         }
         if (is_pair || first) {
-          G[g * CS + 4 * d + ax] = x.p;
-          G[g * CS + 4 * d + 2 + ax] = x.v;
+          G.pos(g, d, ax) = x.p;
+          G.vel(g, d, ax) = x.v;
         }
       }
     }
@@ -434,13 +468,13 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       if (!scored) { if (ckind == RIGHT) TAS += 1.0; else TBS += 1.0; }
       scored = true;
     }
-    wave_sync();
+    grid_sync<SPLITV>();
 
     ev.purge(ci, cj);                                        // cpp:347-352
     {                                                        // re-scan i_ then j_, cpp:355-357 -> 147
       double tt; int jj, kk;
-      if (scan_disc<N, GW>(p, G, ci, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
-      if (cj >= 0 && scan_disc<N, GW>(p, G, cj, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk))
+      if (scan_disc<N, GW, SPLITV>(p, G, ci, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
+      if (cj >= 0 && scan_disc<N, GW, SPLITV>(p, G, cj, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk))
         ev.put(cj, tt, jj, kk, seq++);
     }
   }
@@ -450,8 +484,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   if (lg < 2 * E) {
     const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
-    p.state[(long long)(row + ax) * B + a] = G[kGrid * CS + 4 * e + ax];
-    p.state[(long long)(row + 2 + ax) * B + a] = G[kGrid * CS + 4 * e + 2 + ax];
+    p.state[(long long)(row + ax) * B + a] = G.pos(kGrid, e, ax);
+    p.state[(long long)(row + 2 + ax) * B + a] = G.vel(kGrid, e, ax);
   }
   if (lg == 0) {
     if (NOISE) p.consumed[a] = cur;
@@ -465,7 +499,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       if (n_skipped) atomicAdd(&p.counters[CNT_SKIPPED], (unsigned long long)n_skipped);
     }
   }
-  wave_sync();   // the next step's fill must not overtake this step's column-50 reads
+  grid_sync<SPLITV>();   // the next step's fill must not overtake this step's column-50 reads
   if (stamp && lg == 0) {
     const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
     atomicAdd(&p.stamp_out[STAMP_FILL], ts1 - ts0);

@@ -49,9 +49,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   const int grp = lane / GW, lg = lane % GW;
   const long long a = ((long long)blockIdx.x * kWavesPerBlock + wave) * GPW + grp;
   if (a >= p.B) return;
-  double *G = lds + (wave * GPW + grp) * L::DOUBLES;
+  const GridView<N, false> G{lds + (wave * GPW + grp) * L::DOUBLES, nullptr};
   for (int k = 0; k < p.n_steps; ++k)
-    arena_step_group<N, GW, FAST, NOISE>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
+    arena_step_group<N, GW, FAST, NOISE, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
 }
 
 // Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
@@ -60,13 +60,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
 // a 49-event step only delays the 63 arenas that share its wave.
 // Lane-group width of the hybrid's wave pass: the narrowest power of two that holds the 2E
 // (disc, axis) chains, so 4 (n <= 3) or 2 (n >= 4) flagged arenas are re-run side by side.
-template <int N>
+template <int N, bool SPLITV = false>
 struct HybridGroups {
   static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16 : 32;
   // Arenas re-run side by side = LDS grids per block.  The kernels' register footprint allows 4 waves
   // per CU, so a block may use at most 160 KB / 4 = 40 KB of LDS or residency drops below one wave
   // per SIMD (measured at 7v7: two 24.9 KB grids -> 3 blocks per CU, 1.48e8; one grid -> 1.79e8).
-  static constexpr int GRID_BYTES = 8 * WaveLayout<N>::DOUBLES;
+  static constexpr int GRID_BYTES = 8 * GridView<N, SPLITV>::LDS_DOUBLES;
   static constexpr int FIT = (40 * 1024) / GRID_BYTES;
   static constexpr int GPW = (64 / GW) < FIT ? (64 / GW) : (FIT < 1 ? 1 : FIT);
 };
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
   const long long a0 = (long long)blockIdx.x * 64;
   const long long a = a0 + lane;
   const bool mine = a < p.B;
-  double *G = lds + grp * WaveLayout<N>::DOUBLES;
+  const GridView<N, false> G{lds + grp * WaveLayout<N>::DOUBLES, nullptr};
   unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
   if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < p.n_steps; ++k) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
       m = mm;
       n_rounds++;
       const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
-      if (bit >= 0) arena_step_group<N, GW, FAST>(p, ctl, a0 + bit, G, lg, lane - lg, dm);
+      if (bit >= 0) arena_step_group<N, GW, FAST, false, false>(p, ctl, a0 + bit, G, lg, lane - lg, dm);
     }
     __syncthreads();
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
@@ -124,15 +124,17 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
 template <int N, int MODE>
 __global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
+  constexpr bool SPLITV = N >= 6;                        // velocity rows of the grid in global scratch (measured: +14..18 % at 6v6/7v7 where it doubles the grids per block, -5 % at 4v4/5v5)
   extern __shared__ double lds[];
-  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
+  constexpr int GW = HybridGroups<N, SPLITV>::GW, GPW = HybridGroups<N, SPLITV>::GPW;
   const int lane = threadIdx.x;
   const int grp = lane / GW, lg = lane % GW;
   const long long a0 = (long long)blockIdx.x * 32;
   const long long a = a0 + (lane >> 1);
   const int ax = lane & 1;
   const bool mine = a < p.B;
-  double *G = lds + grp * WaveLayout<N>::DOUBLES;
+  const GridView<N, SPLITV> G{lds + grp * GridView<N, SPLITV>::LDS_DOUBLES,
+                              SPLITV ? p.vgrid + ((long long)blockIdx.x * GPW + grp) * GridView<N, SPLITV>::GV_DOUBLES : nullptr};
   unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
   if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < p.n_steps; ++k) {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) 
       m = mm;
       n_rounds++;
       const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
-      if (bit >= 0) arena_step_group<N, GW, FAST>(p, ctl, a0 + (bit >> 1), G, lg, lane - lg, dm);
+      if (bit >= 0) arena_step_group<N, GW, FAST, false, SPLITV>(p, ctl, a0 + (bit >> 1), G, lg, lane - lg, dm);
     }
     __syncthreads();
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
@@ -286,6 +288,8 @@ struct rgs_sim {
   int *consumed_dev = nullptr;
   unsigned long long *bak_counters = nullptr;
   size_t tape_cap = 0;             // doubles allocated in tape_dev
+  double *vgrid = nullptr;         // split-grid velocity rows (two-lane hybrid, n >= 4)
+  size_t vgrid_cap = 0;
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
 };
 
@@ -497,9 +501,21 @@ int launch_hybrid(rgs_sim *s, const StepArgs &args) {
 }
 
 template <int N>
-int launch_hybrid2(rgs_sim *s, const StepArgs &args) {
+int launch_hybrid2(rgs_sim *s, StepArgs args) {
+  constexpr bool SPLITV = N >= 6;
   const long long blocks = (s->B + 31) / 32;
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
+  const size_t lds = sizeof(double) * GridView<N, SPLITV>::LDS_DOUBLES * HybridGroups<N, SPLITV>::GPW;
+  if (SPLITV) {                                           // velocity rows of every block's grids
+    const size_t need = (size_t)blocks * HybridGroups<N, SPLITV>::GPW * GridView<N, SPLITV>::GV_DOUBLES;
+    if (need > s->vgrid_cap) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      hipFree(s->vgrid);
+      s->vgrid = nullptr; s->vgrid_cap = 0;
+      HIP_TRY(hipMalloc(&s->vgrid, sizeof(double) * need));
+      s->vgrid_cap = need;
+    }
+    args.vgrid = s->vgrid;
+  }
   const bool fast = use_fast_division(s);
   if (fast && is_power_of_two(s->tau_player) && s->one_step_ok)
     hipLaunchKernelGGL((k_step_hybrid2<N, DIV_POW2_ONESTEP>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
@@ -544,7 +560,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.queue = nullptr; a.queue_count = nullptr;
-  a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr;
+  a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr; a.vgrid = nullptr;
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
       a.ctl = ctl_dev + (long long)k * stride;
@@ -696,7 +712,7 @@ int rgs_destroy(rgs_sim *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   hipFree(s->state); hipFree(s->tcur); hipFree(s->tprev);
-  hipFree(s->tape_dev); hipFree(s->bak_state); hipFree(s->bak_tcur); hipFree(s->bak_damage); hipFree(s->consumed_dev); hipFree(s->bak_counters); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
+  hipFree(s->vgrid); hipFree(s->tape_dev); hipFree(s->bak_state); hipFree(s->bak_tcur); hipFree(s->bak_damage); hipFree(s->consumed_dev); hipFree(s->bak_counters); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
