@@ -82,8 +82,6 @@ struct StepArgs {
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]
-  int *queue;                        // hybrid: [B] arena indices needing the event pass
-  int *queue_count;                  // hybrid: [n_steps] or [1]
 };
 
 // State-vector row of disc e's first component (include/SimState.h:14-23; players after the puck).

@@ -20,6 +20,17 @@ namespace {
 
 thread_local std::string g_err;
 
+// Frees device allocations of the self-test entry points on every exit path.
+struct DeviceScratch {
+  std::vector<void *> ptrs;
+  ~DeviceScratch() { for (void *q : ptrs) (void)hipFree(q); }
+  hipError_t alloc(double **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) ptrs.push_back(*out);
+    return e;
+  }
+};
+
 int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
@@ -559,7 +570,6 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.counters = s->counters;
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
-  a.queue = nullptr; a.queue_count = nullptr;
   a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr; a.vgrid = nullptr;
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
@@ -1004,10 +1014,11 @@ int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double t
   HIP_TRY(hipSetDevice(device_id));
   double *a = nullptr, *f = nullptr, *q = nullptr, *o = nullptr;
   const size_t bytes = sizeof(double) * (size_t)n;
-  HIP_TRY(hipMalloc(&a, bytes));
-  HIP_TRY(hipMalloc(&f, bytes));
-  HIP_TRY(hipMalloc(&q, bytes));
-  HIP_TRY(hipMalloc(&o, bytes));
+  DeviceScratch scratch;
+  HIP_TRY(scratch.alloc(&a, bytes));
+  HIP_TRY(scratch.alloc(&f, bytes));
+  HIP_TRY(scratch.alloc(&q, bytes));
+  HIP_TRY(scratch.alloc(&o, bytes));
   HIP_TRY(hipMemcpy(a, a_host, bytes, hipMemcpyHostToDevice));
   const int tb = 256;
   hipLaunchKernelGGL(k_selftest_divtau, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, 0, a, (long long)n, tau,
@@ -1016,7 +1027,6 @@ int rgs_selftest_divtau(int device_id, const double *a_host, int64_t n, double t
   HIP_TRY(hipMemcpy(fast_host, f, bytes, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ieee_host, q, bytes, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(one_host, o, bytes, hipMemcpyDeviceToHost));
-  hipFree(a); hipFree(f); hipFree(q); hipFree(o);
   return RGS_OK;
 }
 
@@ -1026,10 +1036,11 @@ int rgs_selftest_math(int device_id, const double *a_host, const double *b_host,
   HIP_TRY(hipSetDevice(device_id));
   double *a = nullptr, *b = nullptr, *q = nullptr, *r = nullptr;
   const size_t bytes = sizeof(double) * (size_t)n;
-  HIP_TRY(hipMalloc(&a, bytes));
-  HIP_TRY(hipMalloc(&b, bytes));
-  HIP_TRY(hipMalloc(&q, bytes));
-  HIP_TRY(hipMalloc(&r, bytes));
+  DeviceScratch scratch;
+  HIP_TRY(scratch.alloc(&a, bytes));
+  HIP_TRY(scratch.alloc(&b, bytes));
+  HIP_TRY(scratch.alloc(&q, bytes));
+  HIP_TRY(scratch.alloc(&r, bytes));
   HIP_TRY(hipMemcpy(a, a_host, bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b, b_host, bytes, hipMemcpyHostToDevice));
   const int tb = 256;
@@ -1037,7 +1048,6 @@ int rgs_selftest_math(int device_id, const double *a_host, const double *b_host,
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(quot_host, q, bytes, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(sqrt_host, r, bytes, hipMemcpyDeviceToHost));
-  hipFree(a); hipFree(b); hipFree(q); hipFree(r);
   return RGS_OK;
 }
 
