@@ -173,6 +173,9 @@ def main():
 
     if args.stamps:
         sim.stamps(True)
+    if world > 1:                                             # RCCL channel setup happens on first use: not in the timed region
+        src0 = mine if args.backend == "nccl" else mine.cpu()
+        all_gather_states(src0, B * world)
     # ---- warm-up, then the timed region ----------------------------------------------------
     run_steps(0, W)
     barrier()
