@@ -82,10 +82,32 @@ def build(force=False):
     return LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as /opt/rocm's).  If this
+    library were loaded first it would bind to the system copy and a later `import torch` would bring
+    a second HIP runtime into the process: device pointers could then not be passed between the two
+    (bench.py and montecarlo.run_closed_loop_on_device hand torch tensors to the stepper).  Loading
+    torch's copy first -- without importing torch -- makes every later load resolve to that one.
+    Set RGS_USE_SYSTEM_HIP=1 to skip this."""
+    if os.environ.get("RGS_USE_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load the HIP library, failing loudly when it is missing."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "robo_game_py: %s is missing. Build it with `make -C %s` (needs hipcc); "

@@ -161,3 +161,53 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
     if own:
         sim.close()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Closed loop entirely on the device
+# ---------------------------------------------------------------------------------------------------
+
+def chase_policy_torch(state, k, t, speed=4.0):
+    """Every player heads for the puck at `speed` (the contact-rich test policy), on the GPU.
+    state: torch (S, B) float64 on the stepper's device -> controls (P, 2, B)."""
+    import torch
+    P = (state.shape[0] - 6) // 4
+    players = state[6:6 + 4 * P].reshape(P, 4, -1)[:, :2]               # (P, 2, B)
+    d = state[2:4].unsqueeze(0) - players
+    nrm = torch.sqrt((d * d).sum(1, keepdim=True)).clamp_min(1e-300)
+    return speed * d / nrm
+
+
+def mindless_policy_torch(state, k, t):
+    import torch
+    P = (state.shape[0] - 6) // 4
+    u = torch.empty((P, 2, state.shape[1]), dtype=torch.float64, device=state.device)
+    u[:, 0] = math.cos(t)
+    u[:, 1] = math.sin(t)
+    return u
+
+
+def run_closed_loop_on_device(sim, policy, n_steps, dt=None, t0=0.0):
+    """state -> policy -> step, n_steps times, without leaving the GPU.
+
+    sim: a BatchedGameSim already reset; policy(state, k, t) maps a torch (S, B) float64 tensor on the
+    sim's device to a (P, 2, B) tensor.  Per step: one device-to-device copy of the state into the torch
+    tensor, the policy's own kernels, one stepping launch reading the controls in place.  This is the
+    C5-shaped loop (controller output = one (2,) vector per player per step, py/test_dmpc.py:43-47)
+    with the controller on the device.  Returns the final state as a torch tensor.
+    """
+    import torch
+    dev = torch.device("cuda", sim.device)
+    dt = sim.params["dt"] if dt is None else dt
+    state = torch.empty((sim.state_size, sim.n_arenas), dtype=torch.float64, device=dev)
+    t = float(t0)
+    for k in range(n_steps):
+        sim.copy_state_to(state.data_ptr())
+        sim.sync()                                   # the stepper's stream -> visible to torch's stream
+        u = policy(state, k, t).contiguous()
+        torch.cuda.current_stream(dev).synchronize() # torch's stream -> visible to the stepper's stream
+        sim.step_device(u.data_ptr(), 0, 1)
+        t += dt
+    sim.copy_state_to(state.data_ptr())
+    sim.sync()
+    return state

@@ -121,3 +121,28 @@ def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path):
             assert ran.sum() == len(want)
             assert np.array_equal(rec[ran, :R - 1, a], want)
         sim.close()
+
+
+def test_closed_loop_on_device_matches_host_loop(rgp, oracle):
+    """The same chase policy evaluated by torch on the GPU (no PCIe per step) and step by step through
+    the oracle with the controls torch produced: identical trajectories."""
+    torch = pytest.importorskip("torch")
+    from robo_game_py import workloads as w
+    from robo_game_py.montecarlo import chase_policy_torch, run_closed_loop_on_device
+    n, B, K, dt = 2, 64, 60, 0.05
+    x0, _, _ = w.c2_inputs(B, n, seed=21)
+    sim = rgp.BatchedGameSim(B, n)
+    sim.reset(dt, 3, x0)
+    used = []
+
+    def policy(state, k, t):
+        u = chase_policy_torch(state, k, t)
+        used.append(u.cpu().numpy().copy())
+        return u
+
+    final = run_closed_loop_on_device(sim, policy, K).cpu().numpy()
+    assert np.array_equal(final, sim.state())
+    ref = oracle.batch_run(n, x0, np.stack(used), K, dt=dt, winning_score=3, n_threads=8)
+    assert np.array_equal(final, ref["state"])
+    assert ref["stats"]["resolved"] > 100
+    sim.close()
