@@ -45,6 +45,10 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #define GSIM_INV(c) ((c) + C0 >= PKC ? inv_pk : inv_pl)
 #define GSIM_COEF(c) ((c) + C0 >= PKC ? 0.2 : 1.0)
 #define GSIM_IS_PK(c) ((c) + C0 >= PKC)
+// numerator of f's acceleration row: players u - v (cpp:66-67); puck 0 - 0.2*v (cpp:94-95, u is always 0),
+// written as a negation: same value (only the sign of a zero can differ), and the negation is a free
+// source modifier where the subtraction from 0.0 is an instruction.
+#define GSIM_NUM(c, x) (GSIM_IS_PK(c) ? -(0.2 * (x)) : (u[c] - (x)))
 // Division of every chain's a[] by its tau, by compile-time mode:
 //   DIV_IEEE      IEEE '/' everywhere (taus outside div_tau<true>'s domain, or forced)
 //   DIV_MARKSTEIN div_tau<true>'s five steps for every chain
@@ -76,7 +80,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
   }
   // k1 = f(x)
 #pragma unroll
-  GSIM_EACH a[c] = u[c] - GSIM_COEF(c) * v[c];
+  GSIM_EACH a[c] = GSIM_NUM(c, v[c]);
   GSIM_DIV();
 #pragma unroll
   GSIM_EACH { accv[c] = q[c]; accp[c] = v[c]; }                       // k1v, k1p
@@ -84,7 +88,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #pragma unroll
   GSIM_EACH r[c] = v[c] + q[c] * half;                                // x2v (= k2p)
 #pragma unroll
-  GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = u[c] - GSIM_COEF(c) * r[c]; }
+  GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = GSIM_NUM(c, r[c]); }
   GSIM_DIV();
 #pragma unroll
   GSIM_EACH accv[c] = __builtin_fma(q[c], 2.0, accv[c]);
@@ -92,7 +96,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #pragma unroll
   GSIM_EACH r[c] = v[c] + q[c] * half;                                // x3v (= k3p)
 #pragma unroll
-  GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = u[c] - GSIM_COEF(c) * r[c]; }
+  GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = GSIM_NUM(c, r[c]); }
   GSIM_DIV();
 #pragma unroll
   GSIM_EACH accv[c] = __builtin_fma(q[c], 2.0, accv[c]);
@@ -100,7 +104,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #pragma unroll
   GSIM_EACH r[c] = v[c] + q[c] * h;                                   // x4v (= k4p)
 #pragma unroll
-  GSIM_EACH { accp[c] = accp[c] + r[c]; a[c] = u[c] - GSIM_COEF(c) * r[c]; }
+  GSIM_EACH { accp[c] = accp[c] + r[c]; a[c] = GSIM_NUM(c, r[c]); }
   GSIM_DIV();
 #pragma unroll
   GSIM_EACH { p[c] = p[c] + accp[c] * w; v[c] = v[c] + (accv[c] + q[c]) * w; }   // cpp:87
@@ -108,6 +112,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #undef GSIM_DIV_MARK
 #undef GSIM_DIV_ONE
 #undef GSIM_IS_PK
+#undef GSIM_NUM
 #undef GSIM_COEF
 #undef GSIM_INV
 #undef GSIM_TAU
