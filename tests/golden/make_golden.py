@@ -57,5 +57,27 @@ def main():
              50, tau_puck=1.0, tau_player=0.3, player_mass=2.0, puck_mass=0.25)
 
 
+def unit_scenarios():
+    """six single-arena situations side by side, recorded after EVERY step."""
+    K, dt, B = 80, 0.05, 6
+    x0 = np.zeros((4, B))
+    tab = np.zeros((K, 4, 2, B))
+    # 0: free flight (no events): A1 commanded diagonally, puck coasting
+    tab[:, 0, :, 0] = [1.0, -0.5]; x0[:, 0] = [0.0, 0.0, 0.8, 0.3]
+    # 1: A1 into the top wall and held there (repeated wall events, overlap pushes)
+    tab[:, 0, :, 1] = [0.0, 6.0]
+    # 2: A1 head-on into a resting puck (player -> puck impulse, no damage)
+    tab[:, 0, :, 2] = [4.0, 0.0]; x0[:, 2] = [-1.5, 1.25, 0.0, 0.0]
+    # 3: A1 and B1 driven head-on (player <-> player, damage both ways)
+    tab[:, 0, :, 3] = [6.0, 0.0]; tab[:, 2, :, 3] = [-6.0, 0.0]
+    # 4: puck shot into the right goal mouth, then a second goal (scores, puck zeroing, later steps)
+    x0[:, 4] = [3.0, 0.1, 9.0, 0.0]
+    # 5: A1 and A2 pushed against each other for the whole run (sustained contact: steps that end on the
+    #    50-iteration cap, include/GameSim.h:7)
+    tab[:, 0, :, 5] = [0.0, -6.0]; tab[:, 1, :, 5] = [0.0, 6.0]
+    scenario("unit_scenarios_2v2", 2, B, K, dt, 2, tab, x0, 1)
+
+
 if __name__ == "__main__":
+    unit_scenarios()
     main()
