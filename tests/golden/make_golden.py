@@ -72,9 +72,9 @@ def unit_scenarios():
     tab[:, 0, :, 3] = [6.0, 0.0]; tab[:, 2, :, 3] = [-6.0, 0.0]
     # 4: puck shot into the right goal mouth, then a second goal (scores, puck zeroing, later steps)
     x0[:, 4] = [3.0, 0.1, 9.0, 0.0]
-    # 5: A1 and A2 pushed against each other for the whole run (sustained contact: steps that end on the
-    #    50-iteration cap, include/GameSim.h:7)
-    tab[:, 0, :, 5] = [0.0, -6.0]; tab[:, 1, :, 5] = [0.0, 6.0]
+    # 5: the puck squeezed between A1 and the left wall above the goal mouth (sustained contact: steps
+    #    that end on the 50-iteration cap, include/GameSim.h:7)
+    tab[:, 0, :, 5] = [-6.0, 0.0]; x0[:, 5] = [-4.6, 1.25, 0.0, 0.0]
     scenario("unit_scenarios_2v2", 2, B, K, dt, 2, tab, x0, 1)
 
 
