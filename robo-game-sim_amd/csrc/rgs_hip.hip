@@ -73,7 +73,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
 // (disc, axis) chains, so 4 (n <= 3) or 2 (n >= 4) flagged arenas are re-run side by side.
 template <int N, bool SPLITV = false>
 struct HybridGroups {
-  static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16 : 32;
+  // narrowest group (a multiple of 4 lanes, so the carry-out's DPP quad stays aligned) holding the 2E chains
+  static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16
+                            : ((2 * (2 * N + 1) <= 20 && SPLITV) ? 20 : 32);
   // Arenas re-run side by side = LDS grids per block.  The kernels' register footprint allows 4 waves
   // per CU, so a block may use at most 160 KB / 4 = 40 KB of LDS or residency drops below one wave
   // per SIMD (measured at 7v7: two 24.9 KB grids -> 3 blocks per CU, 1.48e8; one grid -> 1.79e8).
@@ -135,7 +137,9 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
 template <int N, int MODE>
 __global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
-  constexpr bool SPLITV = N >= 6;                        // velocity rows of the grid in global scratch (measured: +14..18 % at 6v6/7v7 where it doubles the grids per block, -5 % at 4v4/5v5)
+  // velocity rows of the grid in global scratch: +14..18 % at 6v6/7v7 where it doubles the grids per block;
+  // at 4v4 it makes three 20-lane groups fit; 5v5 (two grids fit either way) loses 5 % with it
+  constexpr bool SPLITV = N >= 6 || N == 4;
   extern __shared__ double lds[];
   constexpr int GW = HybridGroups<N, SPLITV>::GW, GPW = HybridGroups<N, SPLITV>::GPW;
   const int lane = threadIdx.x;
@@ -513,7 +517,7 @@ int launch_hybrid(rgs_sim *s, const StepArgs &args) {
 
 template <int N>
 int launch_hybrid2(rgs_sim *s, StepArgs args) {
-  constexpr bool SPLITV = N >= 6;
+  constexpr bool SPLITV = N >= 6 || N == 4;
   const long long blocks = (s->B + 31) / 32;
   const size_t lds = sizeof(double) * GridView<N, SPLITV>::LDS_DOUBLES * HybridGroups<N, SPLITV>::GPW;
   if (SPLITV) {                                           // velocity rows of every block's grids
