@@ -9,8 +9,9 @@
 //
 // The overlap watch is CONSERVATIVE: it fires on a superset of the reference's tests
 // (cpp:374,397,420,443,471), using squared distances and slightly widened thresholds, so
-// it costs a handful of multiply/compare per disc pair and no sqrt.  A lane whose watch
-// fired commits nothing; its arena is re-run from the step's start state by the
+// it costs a handful of multiply/compare per disc pair and no sqrt; the pair tests run only
+// every few sub-steps, against a radius widened by the travel possible in between (see
+// lane_step).  A lane whose watch fired commits nothing; its arena is re-run from the step's start state by the
 // wave-per-arena pass (gsim_wave.hpp), which implements the reference's event loop
 // exactly.  A lane whose watch stayed silent has, by construction, computed precisely what
 // the reference computes for an event-free step: the same RK4 chain (same rk4_axis code),
@@ -25,11 +26,13 @@ namespace gsim {
 // orders of magnitude to spare (rounding moves these quantities by ~1e-16 relative).
 constexpr double kWatchSlack = 1.0e-9;
 
+// How the lane pass divides by the taus (chosen per launch by the host, see GSIM_DIV below).
+enum DivMode : int { DIV_IEEE = 0, DIV_MARKSTEIN = 1, DIV_PLAYER_POW2 = 2, DIV_POW2_ONESTEP = 3 };
+
 // One RK4 sub-step for M independent chains, written stage-major: every statement below is a
 // loop over the chains, so consecutive instructions belong to different chains and a single
 // wave per SIMD (65 536 arenas = 1024 waves = one per SIMD) still issues back to back instead
-// of waiting out each dependent fp64 latency.  Arithmetic per chain is exactly rk4_axis<FAST>.
-enum DivMode : int { DIV_IEEE = 0, DIV_MARKSTEIN = 1, DIV_PLAYER_POW2 = 2, DIV_POW2_ONESTEP = 3 };
+// of waiting out each dependent fp64 latency.  Arithmetic per chain is exactly rk4_axis<DM>.
 
 // The batch is chains [C0, C0 + M) of the arena's arrays; chains >= PKC belong to the puck.
 template <int MODE, int C0, int M, int PKC>
@@ -50,8 +53,8 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 // source modifier where the subtraction from 0.0 is an instruction.
 #define GSIM_NUM(c, x) (GSIM_IS_PK(c) ? -(0.2 * (x)) : (u[c] - (x)))
 // Division of every chain's a[] by its tau, by compile-time mode:
-//   DIV_IEEE      IEEE '/' everywhere (taus outside div_tau<true>'s domain, or forced)
-//   DIV_MARKSTEIN div_tau<true>'s five steps for every chain
+//   DIV_IEEE      IEEE '/' everywhere (taus outside div_tau<1>'s domain, or forced)
+//   DIV_MARKSTEIN div_tau<1>'s five steps for every chain
 //   DIV_PLAYER_POW2  tau_player is +-2^k (the default 0.5): a/tau = a*(1/tau) exactly -- scaling by a
 //                 power of two is exact and rounds like '/' even into the denormals -- so the 2P
 //                 player chains need one multiply; the puck chains use the five steps.

@@ -1,16 +1,17 @@
-// gsim_wave.hpp -- one lane-group (GW = 16/32/64 lanes of one wavefront) owns one arena.
+// gsim_wave.hpp -- one lane-group (GW = 16/20/32/64 lanes of one wavefront) owns one arena.
 //
 // The whole step of the reference (GameSim::updateSim, src/GameSim.cpp:126-171) for one
-// arena, with the 51-column state grid (state_grid_, include/GameSim.h:46) staged in LDS:
+// arena, with the 51-column state grid (state_grid_, include/GameSim.h:46) staged in LDS
+// (GridView: all of it, or from 6v6 up and at 4v4 only the positions, velocities in L2):
 //
 //   fill      lanes (disc, axis) integrate their own RK4 chain down the 50 sub-steps
 //             (populateStateGrid, cpp:173-217) and write the columns to LDS;
 //   scan      lane <-> grid column: every lane runs the wall / disc-pair overlap tests of
 //             one column (insertCollisions, cpp:360-511); a ballot over the group picks
 //             the first column with an admissible event;
-//   resolve   the earliest event is carried out by the 2 (wall) or 4 (pair) lanes that
-//             own the affected chains, exchanging the partner's values by lane shuffles
-//             (carryOutFirstCollision, cpp:219-358, correctOverlap cpp:581-623);
+//   resolve   the earliest event is carried out by the group's first quad of lanes, which take
+//             over the affected (disc, axis) chains and exchange partner values by DPP
+//             quad_perm (carryOutFirstCollision, cpp:219-358, correctOverlap cpp:581-623);
 //   list      the live events sit in registers, one slot per disc (an event's i_ is unique
 //             in the list), replicated across the group; "stable sort descending, pop
 //             the back" (cpp:227,510, Collision.h:24-30) becomes "minimum time, ties to
