@@ -10,9 +10,7 @@
 #include <vector>
 
 #include "../../include/rgs_hip.h"
-#include "gsim_common.hpp"
-#include "gsim_wave.hpp"
-#include "gsim_lane.hpp"
+#include "gsim_kernels.hpp"
 
 using namespace gsim;
 
@@ -42,205 +40,6 @@ int fail(int code, const std::string &msg) {
     if (e_ != hipSuccess)                                                                  \
       return fail(RGS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
   } while (0)
-
-constexpr int kWavesPerBlock = 4;
-
-// ---------------------------------------------------------------------------------------
-// Kernels
-// ---------------------------------------------------------------------------------------
-
-// One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
-// the SoA arrays (L2-resident) between steps.
-template <int N, int GW, int FAST, bool NOISE = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
-  extern __shared__ double lds[];
-  using L = WaveLayout<N>;
-  constexpr int GPW = 64 / GW;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int grp = lane / GW, lg = lane % GW;
-  const long long a = ((long long)blockIdx.x * kWavesPerBlock + wave) * GPW + grp;
-  if (a >= p.B) return;
-  const GridView<N, false> G{lds + (wave * GPW + grp) * L::DOUBLES, nullptr};
-  for (int k = 0; k < p.n_steps; ++k)
-    arena_step_group<N, GW, FAST, NOISE, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
-}
-
-// Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
-// watch fired are then re-run, one at a time, by the whole wave with the grid in LDS
-// (gsim_wave.hpp).  One wave per block: waves never wait for each other, so an arena stuck in
-// a 49-event step only delays the 63 arenas that share its wave.
-// Lane-group width of the hybrid's wave pass: the narrowest power of two that holds the 2E
-// (disc, axis) chains, so 4 (n <= 3) or 2 (n >= 4) flagged arenas are re-run side by side.
-template <int N, bool SPLITV = false>
-struct HybridGroups {
-  // narrowest group (a multiple of 4 lanes, so the carry-out's DPP quad stays aligned) holding the 2E chains
-  static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16
-                            : ((2 * (2 * N + 1) <= 20 && SPLITV) ? 20 : 32);
-  // Arenas re-run side by side = LDS grids per block.  The kernels' register footprint allows 4 waves
-  // per CU, so a block may use at most 160 KB / 4 = 40 KB of LDS or residency drops below one wave
-  // per SIMD (measured at 7v7: two 24.9 KB grids -> 3 blocks per CU, 1.48e8; one grid -> 1.79e8).
-  static constexpr int GRID_BYTES = 8 * GridView<N, SPLITV>::LDS_DOUBLES;
-  static constexpr int FIT = (40 * 1024) / GRID_BYTES;
-  static constexpr int GPW = (64 / GW) < FIT ? (64 / GW) : (FIT < 1 ? 1 : FIT);
-};
-
-template <int N, int MODE>
-__global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
-  constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
-  extern __shared__ double lds[];
-  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
-  const int lane = threadIdx.x;
-  const int grp = lane / GW, lg = lane % GW;
-  const long long a0 = (long long)blockIdx.x * 64;
-  const long long a = a0 + lane;
-  const bool mine = a < p.B;
-  const GridView<N, false> G{lds + grp * WaveLayout<N>::DOUBLES, nullptr};
-  unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
-  if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
-  for (int k = 0; k < p.n_steps; ++k) {
-    const double *ctl = p.ctl + (long long)k * p.ctl_stride;
-    unsigned discmask = 0u;
-    unsigned long long t0 = 0;
-    if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
-    const bool slow = mine && lane_step<N, MODE>(p, ctl, a, discmask);
-    unsigned long long m = __ballot(slow);
-    if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
-    __syncthreads();                                 // lane-pass stores visible to the wave pass
-    unsigned long long t1 = 0;
-    if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
-    while (m != 0ull) {                              // GPW flagged arenas per round, one per lane group
-      int bit = -1;
-      unsigned long long mm = m;
-#pragma unroll
-      for (int i = 0; i < GPW; ++i) {
-        const int b = mm != 0ull ? __builtin_ctzll(mm) : -1;
-        if (i == grp) bit = b;
-        mm &= mm - 1ull;                             // 0 & anything stays 0
-      }
-      m = mm;
-      n_rounds++;
-      const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
-      if (bit >= 0) arena_step_group<N, GW, FAST, false, false>(p, ctl, a0 + bit, G, lg, lane - lg, dm);
-    }
-    __syncthreads();
-    if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
-  }
-  if (GSIM_STAMPS && p.stamps && lane == 0) {
-    atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
-    atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
-    atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
-    atomicAdd(&p.stamp_out[STAMP_TOTAL], __builtin_amdgcn_s_memtime() - t_begin);
-  }
-}
-
-// Hybrid with two lanes per arena (gsim_lane.hpp, lane_step_split): 32 arenas per wave.
-template <int N, int MODE>
-__global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) {
-  constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
-  // velocity rows of the grid in global scratch: +14..18 % at 6v6/7v7 where it doubles the grids per block;
-  // at 4v4 it makes three 20-lane groups fit; 5v5 (two grids fit either way) loses 5 % with it
-  constexpr bool SPLITV = N >= 6 || N == 4;
-  extern __shared__ double lds[];
-  constexpr int GW = HybridGroups<N, SPLITV>::GW, GPW = HybridGroups<N, SPLITV>::GPW;
-  const int lane = threadIdx.x;
-  const int grp = lane / GW, lg = lane % GW;
-  const long long a0 = (long long)blockIdx.x * 32;
-  const long long a = a0 + (lane >> 1);
-  const int ax = lane & 1;
-  const bool mine = a < p.B;
-  const GridView<N, SPLITV> G{lds + grp * GridView<N, SPLITV>::LDS_DOUBLES,
-                              SPLITV ? p.vgrid + ((long long)blockIdx.x * GPW + grp) * GridView<N, SPLITV>::GV_DOUBLES : nullptr};
-  unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
-  if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
-  for (int k = 0; k < p.n_steps; ++k) {
-    const double *ctl = p.ctl + (long long)k * p.ctl_stride;
-    unsigned discmask = 0u;
-    unsigned long long t0 = 0, t1 = 0;
-    if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
-    const bool slow = mine && lane_step_split<N, MODE>(p, ctl, a, ax, discmask);
-    unsigned long long m = __ballot(slow) & 0x5555555555555555ull;      // one bit per arena (its x lane)
-    if (m != 0ull && lane == 0) atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)__builtin_popcountll(m));
-    __syncthreads();
-    if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
-    while (m != 0ull) {
-      int bit = -1;
-      unsigned long long mm = m;
-#pragma unroll
-      for (int i = 0; i < GPW; ++i) {
-        const int b = mm != 0ull ? __builtin_ctzll(mm) : -1;
-        if (i == grp) bit = b;
-        mm &= mm - 1ull;
-      }
-      m = mm;
-      n_rounds++;
-      const unsigned dm = (unsigned)__shfl((int)discmask, bit < 0 ? 0 : bit);
-      if (bit >= 0) arena_step_group<N, GW, FAST, false, SPLITV>(p, ctl, a0 + (bit >> 1), G, lg, lane - lg, dm);
-    }
-    __syncthreads();
-    if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
-  }
-  if (GSIM_STAMPS && p.stamps && lane == 0) {
-    atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
-    atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
-    atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
-    atomicAdd(&p.stamp_out[STAMP_TOTAL], __builtin_amdgcn_s_memtime() - t_begin);
-  }
-}
-
-// GameSim::reset on the device (src/GameSim.cpp:27-39); players spawn in rows (n = 2: +-Y/4).
-template <int N>
-__global__ void k_reset(double *state, double *tcur, double *damage, const double *x0, int x0_batched,
-                        long long B) {
-  constexpr int P = 2 * N, E = P + 1;
-  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= B) return;
-  state[0 * B + a] = 0.0;
-  state[1 * B + a] = 0.0;
-  for (int c = 0; c < 4; ++c) state[(long long)(2 + c) * B + a] = x0_batched ? x0[(long long)c * B + a] : x0[c];
-  for (int e = 0; e < P; ++e) {
-    const int k = e < N ? e : e - N;
-    const double y = kY / 2.0 - (2 * k + 1) * kY / (2.0 * N);
-    const double x = e < N ? -kX / 4.0 : kX / 4.0;
-    const int row = 6 + 4 * e;
-    state[(long long)(row + 0) * B + a] = x;
-    state[(long long)(row + 1) * B + a] = y;
-    state[(long long)(row + 2) * B + a] = 0.0;
-    state[(long long)(row + 3) * B + a] = 0.0;
-  }
-  for (int q = 0; q < P * P; ++q) damage[(long long)q * B + a] = 0.0;
-  tcur[a] = 0.0;
-  (void)E;
-}
-
-// One log record per arena (src/GameSim.cpp:161-170, include/utils.h:64-76), SoA: rec[R][B] with
-// R = 3 + 2 + 2P + P*P + 1: t, TAS, TBS, puck xy, players' xy, the P "damage.row(k)" blocks exactly as
-// the reference writes them (P contiguous doubles starting at flat column-major element k), and a
-// last row "executed" (1.0 if this step advanced the arena: a decided game logs nothing, cpp:121).
-template <int N>
-__global__ void k_record(const double *state, const double *tcur, const double *damage, double *tprev,
-                         double *rec, long long B) {
-  constexpr int P = 2 * N;
-  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= B) return;
-  int r = 0;
-  const double t = tcur[a];
-  rec[(long long)(r++) * B + a] = t;
-  rec[(long long)(r++) * B + a] = state[0 * B + a];
-  rec[(long long)(r++) * B + a] = state[1 * B + a];
-  rec[(long long)(r++) * B + a] = state[2 * B + a];
-  rec[(long long)(r++) * B + a] = state[3 * B + a];
-  for (int e = 0; e < P; ++e) {
-    rec[(long long)(r++) * B + a] = state[(long long)(6 + 4 * e) * B + a];
-    rec[(long long)(r++) * B + a] = state[(long long)(7 + 4 * e) * B + a];
-  }
-  for (int k = 0; k < P; ++k)
-    for (int q = 0; q < P; ++q) {
-      const int flat = k + q;                         // column-major flat index: row = flat % P, col = flat / P
-      rec[(long long)(r++) * B + a] = damage[(long long)((flat % P) * P + flat / P) * B + a];
-    }
-  rec[(long long)(r++) * B + a] = (t != tprev[a]) ? 1.0 : 0.0;
-  tprev[a] = t;
-}
 
 __global__ void k_undecided(const double *state, long long B, double win, uint8_t *out) {
   const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -402,31 +201,22 @@ double sqrt_threshold(double R, bool strict) {
   return s;
 }
 
-template <int N>
-int launch_wave(rgs_sim *s, const StepArgs &args) {
-  constexpr int GW = 64;
-  constexpr int GPW = 64 / GW;
-  const long long per_block = (long long)kWavesPerBlock * GPW;
-  const long long blocks = (s->B + per_block - 1) / per_block;
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * per_block;
-  if (use_fast_division(s) && s->one_step_ok)
-    hipLaunchKernelGGL((k_step_wave<N, GW, 3>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
-  else if (use_fast_division(s))
-    hipLaunchKernelGGL((k_step_wave<N, GW, 1>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
-  else
-    hipLaunchKernelGGL((k_step_wave<N, GW, 0>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave launch: ") + hipGetErrorString(e));
-  return RGS_OK;
+const GsimOps *gsim_ops(int n) {
+  switch (n) {
+    case 1: return gsim_ops_n1();
+    case 2: return gsim_ops_n2();
+    case 3: return gsim_ops_n3();
+    case 4: return gsim_ops_n4();
+    case 5: return gsim_ops_n5();
+    case 6: return gsim_ops_n6();
+    case 7: return gsim_ops_n7();
+  }
+  return nullptr;
 }
 
-template <int N>
-int launch_wave_noise(rgs_sim *s, const StepArgs &args) {
-  const long long blocks = (s->B + kWavesPerBlock - 1) / kWavesPerBlock;
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * kWavesPerBlock;
-  hipLaunchKernelGGL((k_step_wave<N, 64, 0, true>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, s->stream, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_wave<noise> launch: ") + hipGetErrorString(e));
+int launch_kind(rgs_sim *s, const StepArgs &a, int kind, int mode) {
+  const hipError_t e = gsim_ops(s->n)->step(a, s->stream, kind, mode);
+  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("stepping kernel launch: ") + hipGetErrorString(e));
   return RGS_OK;
 }
 
@@ -467,16 +257,7 @@ int noise_step(rgs_sim *s, StepArgs a) {
     a.tape = s->tape_dev; a.tape_len = T; a.sigma = s->sigma; a.consumed = s->consumed_dev;
     a.n_steps = 1; a.ctl_stride = 0;
     HIP_TRY(hipMemsetAsync(s->consumed_dev, 0, sizeof(int) * B, s->stream));   // decided arenas draw nothing
-    int rc = RGS_ERR_ARG;
-    switch (s->n) {
-      case 1: rc = launch_wave_noise<1>(s, a); break;
-      case 2: rc = launch_wave_noise<2>(s, a); break;
-      case 3: rc = launch_wave_noise<3>(s, a); break;
-      case 4: rc = launch_wave_noise<4>(s, a); break;
-      case 5: rc = launch_wave_noise<5>(s, a); break;
-      case 6: rc = launch_wave_noise<6>(s, a); break;
-      case 7: rc = launch_wave_noise<7>(s, a); break;
-    }
+    int rc = launch_kind(s, a, LAUNCH_WAVE_NOISE, 0);
     if (rc != RGS_OK) return rc;
     s->consumed_host.resize(B);
     HIP_TRY(hipMemcpyAsync(s->consumed_host.data(), s->consumed_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream));
@@ -494,54 +275,6 @@ int noise_step(rgs_sim *s, StepArgs a) {
     HIP_TRY(hipMemcpyAsync(s->damage, s->bak_damage, sizeof(double) * P * P * B, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->counters, s->bak_counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToDevice, s->stream));
   }
-  return RGS_OK;
-}
-
-template <int N>
-int launch_hybrid(rgs_sim *s, const StepArgs &args) {
-  const long long blocks = (s->B + 63) / 64;
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
-  const bool fast = use_fast_division(s);
-  if (fast && is_power_of_two(s->tau_player) && s->one_step_ok)
-    hipLaunchKernelGGL((k_step_hybrid<N, DIV_POW2_ONESTEP>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  else if (fast && is_power_of_two(s->tau_player))
-    hipLaunchKernelGGL((k_step_hybrid<N, DIV_PLAYER_POW2>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  else if (fast)
-    hipLaunchKernelGGL((k_step_hybrid<N, DIV_MARKSTEIN>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  else
-    hipLaunchKernelGGL((k_step_hybrid<N, DIV_IEEE>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_hybrid launch: ") + hipGetErrorString(e));
-  return RGS_OK;
-}
-
-template <int N>
-int launch_hybrid2(rgs_sim *s, StepArgs args) {
-  constexpr bool SPLITV = N >= 6 || N == 4;
-  const long long blocks = (s->B + 31) / 32;
-  const size_t lds = sizeof(double) * GridView<N, SPLITV>::LDS_DOUBLES * HybridGroups<N, SPLITV>::GPW;
-  if (SPLITV) {                                           // velocity rows of every block's grids
-    const size_t need = (size_t)blocks * HybridGroups<N, SPLITV>::GPW * GridView<N, SPLITV>::GV_DOUBLES;
-    if (need > s->vgrid_cap) {
-      HIP_TRY(hipStreamSynchronize(s->stream));
-      hipFree(s->vgrid);
-      s->vgrid = nullptr; s->vgrid_cap = 0;
-      HIP_TRY(hipMalloc(&s->vgrid, sizeof(double) * need));
-      s->vgrid_cap = need;
-    }
-    args.vgrid = s->vgrid;
-  }
-  const bool fast = use_fast_division(s);
-  if (fast && is_power_of_two(s->tau_player) && s->one_step_ok)
-    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_POW2_ONESTEP>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  else if (fast && is_power_of_two(s->tau_player))
-    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_PLAYER_POW2>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  else if (fast)
-    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_MARKSTEIN>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  else
-    hipLaunchKernelGGL((k_step_hybrid2<N, DIV_IEEE>), dim3((unsigned)blocks), dim3(64), lds, s->stream, args);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("k_step_hybrid2 launch: ") + hipGetErrorString(e));
   return RGS_OK;
 }
 
@@ -607,45 +340,24 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
   const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant
                       : (s->auto_wave ? RGS_VARIANT_WAVE : (s->n >= 4 ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID));
+  const bool fast = use_fast_division(s);
+  const int div_mode = !fast ? DIV_IEEE
+                       : (is_power_of_two(s->tau_player) ? (s->one_step_ok ? DIV_POW2_ONESTEP : DIV_PLAYER_POW2) : DIV_MARKSTEIN);
   if (variant == RGS_VARIANT_HYBRID2) {
-    switch (s->n) {
-      case 1: return launch_hybrid2<1>(s, a);
-      case 2: return launch_hybrid2<2>(s, a);
-      case 3: return launch_hybrid2<3>(s, a);
-      case 4: return launch_hybrid2<4>(s, a);
-      case 5: return launch_hybrid2<5>(s, a);
-      case 6: return launch_hybrid2<6>(s, a);
-      case 7: return launch_hybrid2<7>(s, a);
+    const size_t need = gsim_ops(s->n)->vgrid_doubles(s->B);   // velocity rows of every block's grids
+    if (need > s->vgrid_cap) {
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      hipFree(s->vgrid);
+      s->vgrid = nullptr; s->vgrid_cap = 0;
+      HIP_TRY(hipMalloc(&s->vgrid, sizeof(double) * need));
+      s->vgrid_cap = need;
     }
+    a.vgrid = s->vgrid;
+    return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
   }
-  if (variant != RGS_VARIANT_WAVE) {
-    switch (s->n) {
-      case 1: return launch_hybrid<1>(s, a);
-      case 2: return launch_hybrid<2>(s, a);
-      case 3: return launch_hybrid<3>(s, a);
-      case 4: return launch_hybrid<4>(s, a);
-      case 5: return launch_hybrid<5>(s, a);
-      case 6: return launch_hybrid<6>(s, a);
-      case 7: return launch_hybrid<7>(s, a);
-    }
-  }
-  switch (s->n) {
-    case 1: return launch_wave<1>(s, a);
-    case 2: return launch_wave<2>(s, a);
-    case 3: return launch_wave<3>(s, a);
-    case 4: return launch_wave<4>(s, a);
-    case 5: return launch_wave<5>(s, a);
-    case 6: return launch_wave<6>(s, a);
-    case 7: return launch_wave<7>(s, a);
-  }
-  return fail(RGS_ERR_ARG, "n_per_team out of range");
-}
+  if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
+  return launch_kind(s, a, LAUNCH_WAVE, !fast ? 0 : (s->one_step_ok ? 3 : 1));
 
-template <int N>
-void launch_reset(rgs_sim *s, const double *x0_dev, int batched) {
-  const int tb = 256;
-  hipLaunchKernelGGL((k_reset<N>), dim3((unsigned)((s->B + tb - 1) / tb)), dim3(tb), 0, s->stream, s->state,
-                     s->tcur, s->damage, x0_dev, batched, s->B);
 }
 
 int do_reset(rgs_sim *s, const double *x0_host, int batched) {
@@ -654,18 +366,7 @@ int do_reset(rgs_sim *s, const double *x0_host, int batched) {
   double *x0_dev = nullptr;
   HIP_TRY(hipMalloc(&x0_dev, n * sizeof(double)));
   hipError_t e = hipMemcpyAsync(x0_dev, x0_host, n * sizeof(double), hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess) {
-    switch (s->n) {
-      case 1: launch_reset<1>(s, x0_dev, batched); break;
-      case 2: launch_reset<2>(s, x0_dev, batched); break;
-      case 3: launch_reset<3>(s, x0_dev, batched); break;
-      case 4: launch_reset<4>(s, x0_dev, batched); break;
-      case 5: launch_reset<5>(s, x0_dev, batched); break;
-      case 6: launch_reset<6>(s, x0_dev, batched); break;
-      case 7: launch_reset<7>(s, x0_dev, batched); break;
-    }
-    e = hipGetLastError();
-  }
+  if (e == hipSuccess) e = gsim_ops(s->n)->reset(s->state, s->tcur, s->damage, x0_dev, batched, s->B, s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(s->counters, 0, (CNT_N + STAMP_N) * sizeof(unsigned long long), s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   hipFree(x0_dev);
@@ -794,15 +495,7 @@ int rgs_step_device_record(rgs_sim *s, const double *controls_dev, int64_t step_
     int rc = launch_steps(s, controls_dev + (long long)k * step_stride, 0, 1);
     if (rc != RGS_OK) return rc;
     double *rec = rec_dev + (long long)k * R * s->B;
-    switch (s->n) {
-      case 1: hipLaunchKernelGGL((k_record<1>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-      case 2: hipLaunchKernelGGL((k_record<2>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-      case 3: hipLaunchKernelGGL((k_record<3>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-      case 4: hipLaunchKernelGGL((k_record<4>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-      case 5: hipLaunchKernelGGL((k_record<5>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-      case 6: hipLaunchKernelGGL((k_record<6>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-      case 7: hipLaunchKernelGGL((k_record<7>), grid, dim3(tb), 0, s->stream, s->state, s->tcur, s->damage, s->tprev, rec, s->B); break;
-    }
+    HIP_TRY(gsim_ops(s->n)->record(s->state, s->tcur, s->damage, s->tprev, rec, s->B, s->stream));
     HIP_TRY(hipGetLastError());
   }
   return RGS_OK;

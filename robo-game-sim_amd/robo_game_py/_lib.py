@@ -75,7 +75,7 @@ _lib = None
 
 def build(force=False):
     """Compile librgs_hip.so in-tree with hipcc for gfx950 (works without a GPU)."""
-    args = ["make", "-C", CSRC]
+    args = ["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", CSRC]
     if force:
         args.append("-B")
     subprocess.check_call(args + ["librgs_hip.so"], stdout=subprocess.DEVNULL)
