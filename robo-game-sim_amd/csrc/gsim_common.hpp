@@ -25,6 +25,9 @@
 #ifndef GSIM_CHAIN_BATCH
 #define GSIM_CHAIN_BATCH 0
 #endif
+#ifndef GSIM_LANE_HINT
+#define GSIM_LANE_HINT 0
+#endif
 #ifndef GSIM_STAMPS
 #define GSIM_STAMPS 0
 #endif

@@ -185,6 +185,7 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
   const double xthr_pk = kX / 2.0 - kRPuck - kWatchSlack, ythr_pk = kY / 2.0 - kRPuck - kWatchSlack;
   const double rpp = 2.0 * kRPlayer + grow, rpk = kRPlayer + kRPuck + grow;
   const double r2_pp = rpp * rpp * (1.0 + kWatchSlack), r2_pk = rpk * rpk * (1.0 + kWatchSlack);
+  int first_col = 0;                                        // first column of the first block with a flag
   for (int i = 0; i < kGrid; i += we) {
 #pragma nounroll
     for (int j = 0; j < we; ++j) {
@@ -207,6 +208,12 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
         wd[o] |= near;
       }
     }
+    if (GSIM_LANE_HINT) {
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < E; ++e) any |= wd[e];
+      first_col = (first_col == 0 && any) ? i + 1 : first_col;
+    }
   }
   // discmask: bits 0..E-1 = discs whose watch fired, bits 16..21 = first column the wave pass has to
   // scan; the one-lane pass does not track it (measured: costs more here than the shorter scans save at
@@ -218,7 +225,7 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
     watch |= wd[e];
     discmask |= wd[e] ? (1u << e) : 0u;
   }
-  discmask |= 1u << 16;
+  discmask |= (unsigned)((GSIM_LANE_HINT && first_col >= 1) ? first_col : 1) << 16;
   if (guard) discmask = ((1u << E) - 1u) | (1u << 16);
   if (watch) return true;
 
