@@ -316,8 +316,6 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     }
     return RGS_OK;
   }
-  // AUTO: measured on MI355X (profiles/r01): one lane per arena wins up to 3v3; from 4v4 on its
-  // register footprint spills and the two-lanes-per-arena form is faster (4v4 +48 %, 7v7 +11 %).
   // Both hybrids assume that flagged arenas are the exception.  In sustained contact (most arenas
   // flagged every step, many 49-event steps) the plain wave-per-arena kernel, with four waves per SIMD
   // to hide its latency, is faster (measured crossover near 10 % flagged: 76 % flagged 3.4e7 vs 1.9e7).
@@ -338,8 +336,16 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     s->window_steps = 0;
   }
   if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
-  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant
-                      : (s->auto_wave ? RGS_VARIANT_WAVE : (s->n >= 4 ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID));
+  // Which hybrid: measured arena-steps/s (x1e6) on MI355X at a full chip (profiles/r01), one lane per
+  // arena vs two.  The one-lane kernel needs 65 536 arenas to put a wave on every SIMD, the two-lane
+  // kernel 32 768, so small batches shift the balance (C5: 32 768 x 4v4 runs 1.8x faster two-lane,
+  // 65 536 x 4v4 13 % faster one-lane).
+  static const double rate_one[8] = {0, 1390, 1000, 680, 520, 340, 210, 92};
+  static const double rate_two[8] = {0, 800, 650, 480, 460, 314, 241, 184};
+  const double fill_one = s->B >= 65536 ? 1.0 : (double)s->B / 65536.0;
+  const double fill_two = s->B >= 32768 ? 1.0 : (double)s->B / 32768.0;
+  const int hybrid = rate_two[s->n] * fill_two > rate_one[s->n] * fill_one ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID;
+  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : hybrid);
   const bool fast = use_fast_division(s);
   const int div_mode = !fast ? DIV_IEEE
                        : (is_power_of_two(s->tau_player) ? (s->one_step_ok ? DIV_POW2_ONESTEP : DIV_PLAYER_POW2) : DIV_MARKSTEIN);
