@@ -336,16 +336,23 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     s->window_steps = 0;
   }
   if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
-  // Which hybrid: measured arena-steps/s (x1e6) on MI355X at a full chip (profiles/r01), one lane per
-  // arena vs two.  The one-lane kernel needs 65 536 arenas to put a wave on every SIMD, the two-lane
-  // kernel 32 768, so small batches shift the balance (C5: 32 768 x 4v4 runs 1.8x faster two-lane,
-  // 65 536 x 4v4 13 % faster one-lane).
+  // Which kernel: estimated arena-steps/s (x1e6) from rates measured on MI355X (profiles/r01).  The
+  // one-lane hybrid needs 65 536 arenas to put a wave on every SIMD, the two-lane hybrid 32 768; the
+  // wave-per-arena kernel spreads even a few hundred arenas over the whole chip (one wave each) and is
+  // 2-4x faster than either hybrid below ~8k arenas (1024 x 2v2: 5.2e7 vs 2.4e7), modelled as
+  // B / (t0 + B / saturated rate).  Examples: 65 536 x 4v4 one-lane 5.2e8 (two-lane 4.6e8); C5,
+  // 32 768 x 4v4, two-lane 2.7e8 (one-lane 1.5e8); the drop-in GameSim (1 arena) uses the wave kernel.
   static const double rate_one[8] = {0, 1390, 1000, 680, 520, 340, 210, 92};
   static const double rate_two[8] = {0, 800, 650, 480, 460, 314, 241, 184};
-  const double fill_one = s->B >= 65536 ? 1.0 : (double)s->B / 65536.0;
-  const double fill_two = s->B >= 32768 ? 1.0 : (double)s->B / 32768.0;
-  const int hybrid = rate_two[s->n] * fill_two > rate_one[s->n] * fill_one ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID;
-  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : hybrid);
+  static const double wave_sat[8] = {0, 300, 260, 190, 132, 90, 55, 34};
+  static const double wave_t0_us[8] = {0, 15, 15, 15, 15, 22, 30, 40};
+  const double Bd = (double)s->B;
+  const double est_one = rate_one[s->n] * (Bd >= 65536.0 ? 1.0 : Bd / 65536.0);
+  const double est_two = rate_two[s->n] * (Bd >= 32768.0 ? 1.0 : Bd / 32768.0);
+  const double est_wave = Bd / (wave_t0_us[s->n] + Bd / wave_sat[s->n]);
+  int best = est_two > est_one ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID;
+  if (est_wave > (est_two > est_one ? est_two : est_one)) best = RGS_VARIANT_WAVE;
+  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : best);
   const bool fast = use_fast_division(s);
   const int div_mode = !fast ? DIV_IEEE
                        : (is_power_of_two(s->tau_player) ? (s->one_step_ok ? DIV_POW2_ONESTEP : DIV_PLAYER_POW2) : DIV_MARKSTEIN);
