@@ -339,13 +339,23 @@ class GameSim:
     6 to 11 positional arguments are accepted with the C++ defaults of src/GameSim.cpp:21-25.
     `n_per_team` (default 2, the reference's only size) is an extension; run() then takes 2n
     velocity arguments in disc order A1..An, B1..Bn, or one array of shape (2n, 2).
+
+    Every run() is one rgs_step_roundtrip: controls up, one step on the GPU, state down (pinned
+    buffers, one synchronisation).  undecided() and the time are derived on the host from what
+    came back, exactly as the reference derives them (src/GameSim.cpp:57-60, 158).
     """
 
     def __init__(self, n_per_team=2, device=0):
         self._b = BatchedGameSim(1, n_per_team, device)
         self.n_per_team = int(n_per_team)
         self._log = None
-        self._ctl = np.zeros((self._b.players, 2, 1))
+        self._ctl = self._b.pinned((self._b.players, 2, 1))
+        self._st = self._b.pinned((self._b.state_size, 1))
+        self._ctl[...] = 0.0
+        self._win = 3
+        self._dt = 0.05
+        self._t = 0.0
+        self._state = self._b.state()[:, 0].copy()
 
     def __repr__(self):
         return "GameSim Object"                      # src/RoboGamePy.cpp:20-23
@@ -368,16 +378,18 @@ class GameSim:
             raise TypeError("x0_ball must hold 4 doubles")
         a["x0_ball"] = x0
         state = self._b.reset(**a)
+        self._win, self._dt, self._t = a["winning_score"], a["dt"], 0.0
+        self._state = state[:, 0].copy()
         self._close_log()                            # src/GameSim.cpp:48-53
         if a["log"]:
             try:
                 self._log = open(a["logname"], "wb")
             except OSError:
                 self._log = None                     # std::ofstream fails silently (include/utils.h:55-60)
-        return state[:, 0].copy()
+        return self._state.copy()
 
     def undecided(self):
-        return bool(self._b.undecided()[0])
+        return bool(self._state[0] < self._win and self._state[1] < self._win)   # src/GameSim.cpp:57-60
 
     def run(self, *vels):
         P = self._b.players
@@ -387,14 +399,16 @@ class GameSim:
             u = np.stack([np.asarray(v, dtype=np.float64).reshape(2) for v in vels])
         else:
             raise TypeError("run() takes %d velocity arguments of shape (2,) (%d given)" % (P, len(vels)))
-        was_live = self._log is not None and self.undecided()
+        live = self.undecided()
         self._ctl[:, :, 0] = u
-        self._b.step(self._ctl)
-        state = self._b.state()[:, 0].copy()
-        if was_live:                                 # a decided game logs nothing, src/GameSim.cpp:121-123
-            self._log.write(log_record(self._b.time()[0], state, self._b.damage()[:, :, 0]))
-            self._log.flush()
-        return state
+        self._b.step_roundtrip(self._ctl, self._st)
+        self._state = self._st[:, 0].copy()
+        if live:
+            self._t += self._dt                      # t_ += dt_, src/GameSim.cpp:158
+            if self._log is not None:                # a decided game logs nothing, src/GameSim.cpp:121-123
+                self._log.write(log_record(self._t, self._state, self._b.damage()[:, :, 0]))
+                self._log.flush()
+        return self._state.copy()
 
     # extras (not part of the reference binding)
     def damage(self):
@@ -405,3 +419,5 @@ class GameSim:
 
     def set_state(self, state, t=0.0):
         self._b.set_state(np.asarray(state, dtype=np.float64).reshape(-1, 1), t)
+        self._state = np.asarray(state, dtype=np.float64).reshape(-1).copy()
+        self._t = float(t)
