@@ -462,6 +462,34 @@ def test_parameter_fuzz(rgp, oracle, seed):
         sim.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_pathological_inputs_neither_hang_nor_diverge(rgp, oracle, variant):
+    """NaN / inf / 1e200 controls and states, dt = 0, a tiny tau: every loop of the kernels is bounded
+    and every grid index clamped, so the step returns, and what it returns equals the oracle's result
+    value for value (NaN where the oracle has NaN)."""
+    n, B, K = 2, 96, 12
+    rng = np.random.default_rng(5)
+    x0 = np.stack([rng.uniform(-3, 3, B), rng.uniform(-1.5, 1.5, B), rng.uniform(-2, 2, B), rng.uniform(-2, 2, B)])
+    table = rng.uniform(-6, 6, (K, 4, 2, B))
+    table[:, 0, 0, 0:8] = np.nan
+    table[3:, 1, 1, 8:16] = np.inf
+    table[:, 2, :, 16:24] = 1e200
+    table[:, 3, 0, 24:32] = -1e308
+    x0[2, 32:40] = 1e150                                     # absurd puck speed
+    x0[0, 40:44] = np.nan
+    for dt, phys in ((0.05, {}), (0.0, {}), (0.05, dict(tau_puck=1e-12, tau_player=1e-9)), (1e6, {})):
+        ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=3, n_threads=4, **phys)
+        sim = rgp.BatchedGameSim(B, n)
+        sim.set_variant(variant)
+        sim.reset(dt, 3, x0, 0.0, False, "", 0, phys.get("tau_puck", 0.1), phys.get("tau_player", 0.5), 1.0, 0.5)
+        got = sim.run_table(table)
+        sim.close()
+        with np.errstate(all="ignore"):
+            same = (got == ref["state"]) | (np.isnan(got) & np.isnan(ref["state"]))
+        assert same.all(), "dt=%g %r: %d values differ, arenas %s" % (dt, phys, int((~same).sum()),
+                                                                      sorted(set(np.argwhere(~same)[:, 1].tolist()))[:10])
+
+
 def test_auto_variant_switches_in_sustained_contact(rgp, oracle):
     """AUTO watches the event counters between launches: a jammed arena set (everybody pushed to the
     centre) makes it prefer the wave-per-arena kernel, calm play brings the hybrid back; the states are
