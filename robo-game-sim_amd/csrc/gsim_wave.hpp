@@ -324,6 +324,33 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   int seq = 0, base = 1, counter = 0;
   bool scored = false;
   unsigned n_resolved = 0, n_skipped = 0, n_overflow = 0;
+  if ((discmask & 0xFFFFu) == 0xFFFFu) {
+    // No lane pass ran before this (wave-per-arena kernel): derive the per-disc flags from the grid
+    // itself -- lane <-> column, the reference's own overlap predicates (cpp:374,397,420,443,471) for
+    // every disc and pair of the column, OR-ed over the columns.  A disc without a flag has no
+    // candidate at any column, so its first scan is skipped (one pre-pass instead of E scans).
+    unsigned mine = 0u;
+    for (int g = 1 + lg; g <= kGrid; g += GW) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const double rad = disc_radius<N>(e);
+        const double px = G.pos(g, e, 0), py = G.pos(g, e, 1);
+        const bool wall = (py + rad >= kY / 2.0) || (py - rad <= -kY / 2.0) || (px + rad >= kX / 2.0) ||
+                          (px - rad <= -kX / 2.0);
+        mine |= wall ? (1u << e) : 0u;
+#pragma unroll
+        for (int o = e + 1; o < E; ++o) {
+          const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
+          const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
+          mine |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
+        }
+      }
+    }
+    unsigned all = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) all |= group_ballot<GW>(((mine >> e) & 1u) != 0u, gbase) != 0ull ? (1u << e) : 0u;
+    discmask = all | (1u << 16);
+  }
   int scan_from = (int)((discmask >> 16) & 63u);
   scan_from = scan_from < 1 ? 1 : (scan_from > kGrid ? kGrid : scan_from);
 #pragma unroll

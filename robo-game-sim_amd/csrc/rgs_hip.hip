@@ -344,8 +344,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   // 32 768 x 4v4, two-lane 2.7e8 (one-lane 1.5e8); the drop-in GameSim (1 arena) uses the wave kernel.
   static const double rate_one[8] = {0, 1390, 1000, 680, 520, 340, 210, 92};
   static const double rate_two[8] = {0, 800, 650, 480, 460, 314, 241, 184};
-  static const double wave_sat[8] = {0, 300, 260, 190, 132, 90, 55, 34};
-  static const double wave_t0_us[8] = {0, 15, 15, 15, 15, 22, 30, 40};
+  static const double wave_sat[8] = {0, 320, 280, 230, 186, 130, 90, 62};
+  static const double wave_t0_us[8] = {0, 13, 13, 13, 12, 12, 11, 10};
   const double Bd = (double)s->B;
   const double est_one = rate_one[s->n] * (Bd >= 65536.0 ? 1.0 : Bd / 65536.0);
   const double est_two = rate_two[s->n] * (Bd >= 32768.0 ? 1.0 : Bd / 32768.0);
