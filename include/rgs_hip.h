@@ -77,6 +77,12 @@ int rgs_step(rgs_sim *sim, const double *controls_host);
  * handle's stream; rgs_sync() or any rgs_get_* waits for it. */
 int rgs_step_device(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps);
 
+/* rgs_step_device with snapshots: after every rec_every-th step of this call the state [S][B] is copied
+ * to traj_dev[(k / rec_every) - 1] (device memory, floor(n_steps / rec_every) snapshots), inside the
+ * same fused launch. */
+int rgs_step_device_traj(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps, int rec_every,
+                         double *traj_dev);
+
 /* Stepping with the reference's log record captured after every step (src/GameSim.cpp:161-170,
  * include/utils.h:64-76).  rec_dev: [n_steps][R][B] doubles on the device, R =
  * rgs_record_size(n) = 3 + 2 + 2P + P*P + 1: t, TAS, TBS, puck xy, players' xy, the P damage blocks in

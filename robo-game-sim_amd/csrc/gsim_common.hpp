@@ -81,6 +81,10 @@ struct StepArgs {
   const double *tape;
   int tape_len;
   int *consumed;                     // [B] draws used by this step (> tape_len: tape too short, redo)
+  // trajectory snapshots inside a fused launch: after step k (1-based, counted within the launch) with
+  // k % traj_every == 0 the state of every arena is copied to traj[(k/traj_every - 1)][S][B]
+  double *traj;
+  int traj_every;
   double *vgrid;                     // two-lane hybrid, n >= 4: velocity rows of the grids (GridView<N, true>)
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
@@ -197,6 +201,16 @@ __device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, 
   r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;
   r.v = x.v + (__builtin_fma(k3v, 2.0, __builtin_fma(k2v, 2.0, k1v)) + k4v) * w;
   return r;
+}
+
+// Snapshot of arena a's state rows into the trajectory buffer (see StepArgs::traj).  Called by the
+// `nl` lanes that own the arena after its step k0 (0-based) is complete and visible.
+template <int N>
+__device__ __forceinline__ void snapshot_state(const StepArgs &p, long long a, int k0, int lane, int nl) {
+  if (p.traj == nullptr || (k0 + 1) % p.traj_every != 0) return;
+  constexpr int S = 2 + 4 * (2 * N + 1);
+  double *dst = p.traj + (long long)((k0 + 1) / p.traj_every - 1) * S * p.B;
+  for (int r = lane; r < S; r += nl) dst[(long long)r * p.B + a] = p.state[(long long)r * p.B + a];
 }
 
 // Orders LDS traffic between lanes of ONE wavefront: LDS operations of a wave

@@ -26,8 +26,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
   const long long a = ((long long)blockIdx.x * kWavesPerBlock + wave) * GPW + grp;
   if (a >= p.B) return;
   const GridView<N, false> G{lds + (wave * GPW + grp) * L::DOUBLES, nullptr};
-  for (int k = 0; k < p.n_steps; ++k)
+  for (int k = 0; k < p.n_steps; ++k) {
     arena_step_group<N, GW, FAST, NOISE, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
+    if (p.traj != nullptr) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the commit's stores, then the copy's loads
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      snapshot_state<N>(p, a, k, lg, GW);
+    }
+  }
 }
 
 // Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
     }
     __syncthreads();
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
+    if (mine) snapshot_state<N>(p, a, k, 0, 1);
   }
   if (GSIM_STAMPS && p.stamps && lane == 0) {
     atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) 
     }
     __syncthreads();
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
+    if (mine) snapshot_state<N>(p, a, k, ax, 2);
   }
   if (GSIM_STAMPS && p.stamps && lane == 0) {
     atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);

@@ -278,7 +278,8 @@ int noise_step(rgs_sim *s, StepArgs a) {
   return RGS_OK;
 }
 
-int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps) {
+int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps, double *traj = nullptr,
+                 int traj_every = 0) {
   StepArgs a;
   a.dt = s->dt; a.dt_col = s->dt_col;
   a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
@@ -308,10 +309,15 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr; a.vgrid = nullptr;
+  a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
       a.ctl = ctl_dev + (long long)k * stride;
-      int rc = noise_step(s, a);
+      const bool snap = traj != nullptr && (k + 1) % a.traj_every == 0;   // one step per launch here
+      StepArgs b = a;
+      b.traj = snap ? traj + (long long)((k + 1) / a.traj_every - 1) * s->S * s->B : nullptr;
+      b.traj_every = 1;
+      int rc = noise_step(s, b);
       if (rc != RGS_OK) return rc;
     }
     return RGS_OK;
@@ -493,6 +499,15 @@ int rgs_step_device(rgs_sim *s, const double *controls_dev, int64_t step_stride,
   if (n_steps == 0) return RGS_OK;
   HIP_TRY(hipSetDevice(s->device));
   return launch_steps(s, controls_dev, step_stride, n_steps);
+}
+
+int rgs_step_device_traj(rgs_sim *s, const double *controls_dev, int64_t step_stride, int n_steps, int rec_every,
+                         double *traj_dev) {
+  if (!s || !controls_dev || !traj_dev || n_steps < 0 || step_stride < 0 || rec_every < 1)
+    return fail(RGS_ERR_ARG, "rgs_step_device_traj: bad argument");
+  if (n_steps == 0) return RGS_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  return launch_steps(s, controls_dev, step_stride, n_steps, traj_dev, rec_every);
 }
 
 int rgs_record_size(int n_per_team) { return 3 + 2 + 4 * n_per_team + 4 * n_per_team * n_per_team + 1; }

@@ -216,6 +216,27 @@ class BatchedGameSim:
             buf.free()
         return self.state()
 
+    def run_table_traj(self, table, rec_every):
+        """Step through a host control table (K, P, 2, B) in ONE fused launch and return the state after
+        every rec_every-th step: array (K // rec_every, S, B)."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        K = t.shape[0]
+        if t.shape[1:] != (self.players, 2, self.n_arenas):
+            raise TypeError("table must have shape (K, %d, 2, %d)" % (self.players, self.n_arenas))
+        n_rec = K // int(rec_every)
+        stride = self.players * 2 * self.n_arenas
+        cbuf = self.alloc(K * stride)
+        tbuf = self.alloc(max(1, n_rec) * self.state_size * self.n_arenas)
+        try:
+            cbuf.upload(t)
+            _lib.check(self._L.rgs_step_device_traj(self._h, C.c_void_p(cbuf.ptr), stride, K, int(rec_every),
+                                                    C.c_void_p(tbuf.ptr)))
+            out = tbuf.download(n_rec * self.state_size * self.n_arenas).reshape(n_rec, self.state_size, self.n_arenas)
+        finally:
+            cbuf.free()
+            tbuf.free()
+        return out
+
     def record_size(self):
         return int(self._L.rgs_record_size(self.n_per_team))
 

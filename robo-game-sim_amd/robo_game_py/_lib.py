@@ -32,6 +32,7 @@ SIGNATURES = {
                             C.c_double, C.c_double, C.c_double]),
     "rgs_step": (C.c_int, [_vp, _dp]),
     "rgs_step_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "rgs_step_device_traj": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "rgs_record_size": (C.c_int, [C.c_int]),
     "rgs_step_device_record": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
     "rgs_sync": (C.c_int, [_vp]),

@@ -490,6 +490,25 @@ def test_pathological_inputs_neither_hang_nor_diverge(rgp, oracle, variant):
                                                                       sorted(set(np.argwhere(~same)[:, 1].tolist()))[:10])
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("n", [2, 4])
+def test_in_kernel_trajectory_snapshots(rgp, oracle, n, variant):
+    """State snapshots taken inside one fused launch equal the oracle's recorded trajectory."""
+    from robo_game_py import workloads as w
+    B, K, rec = 200, 120, 7
+    x0, _, _ = w.c2_inputs(B, n, seed=12)
+    table = w.random_hold_controls(2 * n, B, K, 8.0, hold=9, seed=4)
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_variant(variant)
+    sim.reset(0.05, 3, x0)
+    traj = sim.run_table_traj(table, rec)
+    ref = oracle.batch_run(n, x0, table, K, dt=0.05, winning_score=3, rec_every=rec, n_threads=8)
+    assert traj.shape == ref["traj"].shape == (K // rec, 2 + 4 * (2 * n + 1), B)
+    assert_same(traj, ref["traj"], "in-kernel snapshots")
+    assert_same(sim.state(), ref["state"], "final state")
+    sim.close()
+
+
 def test_auto_variant_switches_in_sustained_contact(rgp, oracle):
     """AUTO watches the event counters between launches: a jammed arena set (everybody pushed to the
     centre) makes it prefer the wave-per-arena kernel, calm play brings the hybrid back; the states are
