@@ -19,6 +19,9 @@
 #ifndef GSIM_H2_WAVES
 #define GSIM_H2_WAVES 1
 #endif
+#ifndef GSIM_H2_LDS_KB
+#define GSIM_H2_LDS_KB 40
+#endif
 #ifndef GSIM_H1_WAVES
 #define GSIM_H1_WAVES 1
 #endif
@@ -75,6 +78,7 @@ struct StepArgs {
   long long ctl_stride;              // doubles between consecutive steps' controls
   int n_steps;
   int watch_every;                   // lane pass: overlap watch every 5th column (1 = every column)
+  int wall_ends;                     // lane pass: wall watch at column 50 only (monotone-coordinate argument, gsim_lane.hpp)
   // noise > 0 (wave kernel only): w_stdev_ (cpp:30) and the per-arena tape of N(0,1) draws the host
   // generated with the reference's own engine/distribution (cpp:3,41,66-67); tape[a*tape_len + k].
   double sigma;

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
 // a 49-event step only delays the 63 arenas that share its wave.
 // Lane-group width of the hybrid's wave pass: the narrowest power of two that holds the 2E
 // (disc, axis) chains, so 4 (n <= 3) or 2 (n >= 4) flagged arenas are re-run side by side.
-template <int N, bool SPLITV = false>
+template <int N, bool SPLITV = false, int BUDGET_KB = 40>
 struct HybridGroups {
   // narrowest group (a multiple of 4 lanes, so the carry-out's DPP quad stays aligned) holding the 2E chains
   static constexpr int GW = (2 * (2 * N + 1) <= 16 && !GSIM_WIDE_GROUPS) ? 16
@@ -51,7 +51,7 @@ struct HybridGroups {
   // per CU, so a block may use at most 160 KB / 4 = 40 KB of LDS or residency drops below one wave
   // per SIMD (measured at 7v7: two 24.9 KB grids -> 3 blocks per CU, 1.48e8; one grid -> 1.79e8).
   static constexpr int GRID_BYTES = 8 * GridView<N, SPLITV>::LDS_DOUBLES;
-  static constexpr int FIT = (40 * 1024) / GRID_BYTES;
+  static constexpr int FIT = (BUDGET_KB * 1024) / GRID_BYTES;
   static constexpr int GPW = (64 / GW) < FIT ? (64 / GW) : (FIT < 1 ? 1 : FIT);
 };
 
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
 template <int N>
 struct Hybrid2Split {
   static constexpr bool value = N >= 6 || N == 4;
+  static constexpr int LDS_KB = GSIM_H2_LDS_KB;
 };
 
 template <int N, int MODE>
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) 
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   constexpr bool SPLITV = Hybrid2Split<N>::value;        // velocity rows of the grid in global scratch
   extern __shared__ double lds[];
-  constexpr int GW = HybridGroups<N, SPLITV>::GW, GPW = HybridGroups<N, SPLITV>::GPW;
+  using HG = HybridGroups<N, SPLITV, Hybrid2Split<N>::LDS_KB>;
+  constexpr int GW = HG::GW, GPW = HG::GPW;
   const int lane = threadIdx.x;
   const int grp = lane / GW, lg = lane % GW;
   const long long a0 = (long long)blockIdx.x * 32;

@@ -185,16 +185,38 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
   const double xthr_pk = kX / 2.0 - kRPuck - kWatchSlack, ythr_pk = kY / 2.0 - kRPuck - kWatchSlack;
   const double rpp = 2.0 * kRPlayer + grow, rpk = kRPlayer + kRPuck + grow;
   const double r2_pp = rpp * rpp * (1.0 + kWatchSlack), r2_pk = rpk * rpk * (1.0 + kWatchSlack);
+  // Wall watch at the end points (p.wall_ends, same host check as the sparse pair watch).  A wall event
+  // at column i needs the disc inside the wall zone at i while moving TOWARDS that wall at i-1
+  // (cpp:374-392).  With v0 and u of one sign (or either zero) every stage velocity of every sub-step
+  // keeps that sign, so the coordinate is monotone over the step: "in the zone and moving towards the
+  // wall" at any column implies "in the zone" at column 50, which is the only column tested.  A chain
+  // whose velocity may reverse (v0 and u of opposite signs) travels at most |v0|*dt in v0's direction
+  // before it does (its speed only drops until then): it is flagged up front when that reaches the zone
+  // of the wall it is heading for.  NaNs end up in column 50 and fail `<`.
+  const bool wall_ends = p.wall_ends != 0;
+  if (wall_ends) {
+    const double reach = 1.001 * p.dt;                      // x |v0|: the speed only drops until the reversal
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double xthr = e == PK ? xthr_pk : xthr_pl, ythr = e == PK ? ythr_pk : ythr_pl;
+      const double qx = pos[2 * e] + reach * vel[2 * e], qy = pos[2 * e + 1] + reach * vel[2 * e + 1];
+      wd[e] |= (vel[2 * e] > 0.0 && u[2 * e] < 0.0 && !(qx < xthr)) || (vel[2 * e] < 0.0 && u[2 * e] > 0.0 && !(-qx < xthr)) ||
+               (vel[2 * e + 1] > 0.0 && u[2 * e + 1] < 0.0 && !(qy < ythr)) ||
+               (vel[2 * e + 1] < 0.0 && u[2 * e + 1] > 0.0 && !(-qy < ythr));
+    }
+  }
   int first_col = 0;                                        // first column of the first block with a flag
   for (int i = 0; i < kGrid; i += we) {
 #pragma nounroll
     for (int j = 0; j < we; ++j) {
       rk4_all_chains<MODE, M, 2 * PK>(pos, vel, u, p.tau_player, p.inv_tau_player, p.tau_puck, p.inv_tau_puck, dt_col);
+      if (!wall_ends) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const double xthr = e == PK ? xthr_pk : xthr_pl, ythr = e == PK ? ythr_pk : ythr_pl;
-        // NaN positions must not slip through as "no overlap": !(x < thr) is true for NaN
-        wd[e] |= !(__builtin_fabs(pos[2 * e]) < xthr) || !(__builtin_fabs(pos[2 * e + 1]) < ythr);
+        for (int e = 0; e < E; ++e) {
+          const double xthr = e == PK ? xthr_pk : xthr_pl, ythr = e == PK ? ythr_pk : ythr_pl;
+          // NaN positions must not slip through as "no overlap": !(x < thr) is true for NaN
+          wd[e] |= !(__builtin_fabs(pos[2 * e]) < xthr) || !(__builtin_fabs(pos[2 * e + 1]) < ythr);
+        }
       }
     }
 #pragma unroll
@@ -213,6 +235,13 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
 #pragma unroll
       for (int e = 0; e < E; ++e) any |= wd[e];
       first_col = (first_col == 0 && any) ? i + 1 : first_col;
+    }
+  }
+  if (wall_ends) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double xthr = e == PK ? xthr_pk : xthr_pl, ythr = e == PK ? ythr_pk : ythr_pl;
+      wd[e] |= !(__builtin_fabs(pos[2 * e]) < xthr) || !(__builtin_fabs(pos[2 * e + 1]) < ythr);
     }
   }
   // discmask: bits 0..E-1 = discs whose watch fired, bits 16..21 = first column the wave pass has to
@@ -290,13 +319,27 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
   const double thr_pl = half_extent - kRPlayer - kWatchSlack, thr_pk = half_extent - kRPuck - kWatchSlack;
   const double rpp = 2.0 * kRPlayer + grow, rpk = kRPlayer + kRPuck + grow;
   const double r2_pp = rpp * rpp * (1.0 + kWatchSlack), r2_pk = rpk * rpk * (1.0 + kWatchSlack);
+  const bool wall_ends = p.wall_ends != 0;                  // see lane_step
+  bool wall_flag = false;                                   // a wall flag carries no column: scans start at 1
+  if (wall_ends) {
+    const double reach = 1.001 * p.dt;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double q = pos[e] + reach * vel[e], thr = e == PK ? thr_pk : thr_pl;
+      const bool f = (vel[e] > 0.0 && u[e] < 0.0 && !(q < thr)) || (vel[e] < 0.0 && u[e] > 0.0 && !(-q < thr));
+      wd[e] |= f;
+      wall_flag |= f;
+    }
+  }
   int first_col = 0;
   for (int i = 0; i < kGrid; i += we) {
 #pragma nounroll
     for (int j = 0; j < we; ++j) {
       rk4_all_chains<MODE, E, PK>(pos, vel, u, p.tau_player, p.inv_tau_player, p.tau_puck, p.inv_tau_puck, dt_col);
+      if (!wall_ends) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) wd[e] |= !(__builtin_fabs(pos[e]) < (e == PK ? thr_pk : thr_pl));   // NaN counts as overlap
+        for (int e = 0; e < E; ++e) wd[e] |= !(__builtin_fabs(pos[e]) < (e == PK ? thr_pk : thr_pl));   // NaN counts as overlap
+      }
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -315,6 +358,14 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
     for (int e = 0; e < E; ++e) any |= wd[e];
     first_col = (first_col == 0 && any) ? i + 1 : first_col;
   }
+  if (wall_ends) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool f = !(__builtin_fabs(pos[e]) < (e == PK ? thr_pk : thr_pl));
+      wd[e] |= f;
+      wall_flag |= f;
+    }
+  }
   unsigned bits = guard ? ((1u << E) - 1u) : 0u;
 #pragma unroll
   for (int e = 0; e < E; ++e) bits |= wd[e] ? (1u << e) : 0u;
@@ -322,7 +373,9 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
   unsigned fc = (unsigned)(first_col < 1 ? kGrid : first_col);           // the earlier of the two lanes' first blocks
   const unsigned fo = quad_xor1_u32(fc);
   fc = fo < fc ? fo : fc;
-  if (guard || quad_xor1_u32(guard ? 1u : 0u) != 0u) fc = 1u;
+  const bool from_one = guard || wall_flag;
+  const unsigned other_from_one = quad_xor1_u32(from_one ? 1u : 0u);   // exchanged before any branch: both lanes active
+  if (from_one || other_from_one != 0u) fc = 1u;
   discmask = bits | (fc << 16);
   if (bits != 0u) return true;
 

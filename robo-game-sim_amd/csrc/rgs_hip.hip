@@ -304,6 +304,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
       else we = 4.0 * s->dt_col <= 1.0e-3 ? 5 : (s->dt_col <= 1.0e-3 ? 2 : 1);
     }
     a.watch_every = we;
+    a.wall_ends = ok ? 1 : 0;
   }
   a.counters = s->counters;
   a.stamps = s->stamps ? 1 : 0;

@@ -26,7 +26,7 @@ template <int MODE>
 hipError_t launch_hybrid2_mode(const StepArgs &args, hipStream_t stream) {
   constexpr bool SPLITV = Hybrid2Split<N>::value;
   const long long blocks = (args.B + 31) / 32;
-  const size_t lds = sizeof(double) * GridView<N, SPLITV>::LDS_DOUBLES * HybridGroups<N, SPLITV>::GPW;
+  const size_t lds = sizeof(double) * GridView<N, SPLITV>::LDS_DOUBLES * HybridGroups<N, SPLITV, Hybrid2Split<N>::LDS_KB>::GPW;
   hipLaunchKernelGGL((k_step_hybrid2<N, MODE>), dim3((unsigned)blocks), dim3(64), lds, stream, args);
   return hipGetLastError();
 }
@@ -80,7 +80,7 @@ size_t vgrid_doubles(long long B) {
   constexpr bool SPLITV = Hybrid2Split<N>::value;
   if (!SPLITV) return 0;
   const long long blocks = (B + 31) / 32;
-  return (size_t)blocks * HybridGroups<N, SPLITV>::GPW * GridView<N, SPLITV>::GV_DOUBLES;
+  return (size_t)blocks * HybridGroups<N, SPLITV, Hybrid2Split<N>::LDS_KB>::GPW * GridView<N, SPLITV>::GV_DOUBLES;
 }
 
 const GsimOps kOps = {step, reset, record, vgrid_doubles};

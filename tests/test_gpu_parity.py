@@ -544,3 +544,88 @@ def test_noise_is_limited_not_faked(rgp):
     with pytest.raises(rgp.RgsError):
         sim.reset(0.05, 3, np.zeros(4), 0.1)
     sim.close()
+
+
+def oracle_from_state(oracle, n, st, table, dt, win=3):
+    """Per-arena oracle runs started from an arbitrary state (batch_run always starts from a reset)."""
+    K, P, _, B = table.shape
+    out = np.zeros_like(st)
+    stats = {}
+    for a in range(B):
+        o = oracle.OracleGameSim(n)
+        o.reset(dt, win, np.zeros(4))
+        o.set_state(st[:, a].copy(), 0.0)
+        for k in range(K):
+            out[:, a] = o.run(*[table[k, q, :, a].copy() for q in range(P)])
+        for key, val in o.stats().items():
+            stats[key] = stats.get(key, 0) + val
+    return out, stats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_division_guard_on_one_axis_only(rgp, oracle, variant):
+    """A control far below the fast-division window on ONE axis trips the guard in one lane of the
+    two-lane pass only; the arena must still be re-run from column 1 (an early wall bounce of another
+    disc is otherwise found late).  Regression: the lanes exchanged the flag inside a short-circuited
+    condition, i.e. with the sending lane masked off."""
+    n, B, K, dt = 2, 64, 6, 0.02
+    x0 = np.zeros((4, B))
+    table = np.zeros((K, 4, 2, B))
+    table[:, 0, 1, :] = 1e-250                               # A1's y command: outside the window, x is not
+    table[:, 3, 1, :] = -5.0                                 # B2 is pushed into the bottom wall
+    st = np.zeros((22, B))
+    st[6:10] = np.array([[-2.5], [1.25], [0.0], [0.0]])
+    st[10:14] = np.array([[-2.5], [-1.25], [0.0], [0.0]])
+    st[14:18] = np.array([[2.5], [1.25], [0.0], [0.0]])
+    st[18] = 2.5
+    st[19] = -2.29 + 0.004 * np.arange(B) / B               # 1 .. 5 mm above the wall zone
+    st[21] = -4.4
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_variant(variant)
+    sim.reset(dt, 3, x0)
+    sim.set_state(st)
+    got = sim.run_table(table)
+    c = sim.counters()
+    sim.close()
+    ref, stats = oracle_from_state(oracle, n, st, table, dt)
+    assert c["resolved"] == stats["resolved"] and c["resolved"] >= B
+    assert_same(got, ref, "one-axis guard")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("dt", [0.01, 0.05])
+def test_wall_watch_at_grazing_and_reversing_approaches(rgp, oracle, variant, dt):
+    """The lane pass tests walls at column 50 only, plus an up-front bound for chains whose velocity
+    reverses inside the step.  Discs that dip into a wall zone and come back out within one step
+    (command opposite to the velocity), that stop just short of it, or that sit inside it moving away
+    are the cases that rule has to get right."""
+    n, B, K = 2, 1024, 3
+    rng = np.random.default_rng(77)
+    x0 = np.zeros((4, B))
+    st = np.zeros((22, B))
+    st[6:10] = np.array([[-2.5], [0.0], [0.0], [0.0]])
+    st[10:14] = np.array([[-1.0], [0.0], [0.0], [0.0]])
+    st[14:18] = np.array([[1.0], [0.0], [0.0], [0.0]])
+    st[18:22] = np.array([[3.5], [0.0], [0.0], [0.0]])
+    st[2] = 0.0; st[3] = 1.5                                 # puck parked away from everything
+    v = rng.uniform(0.2, 6.0, B)                             # A1 flies at the top wall ...
+    gap = rng.uniform(-0.002, 1.2, B) * v * dt               # ... from where it does / does not reach the zone
+    st[7] = 2.3 - gap
+    st[9] = v
+    table = np.zeros((K, 4, 2, B))
+    table[:, 0, 1, :] = -rng.uniform(0.0, 300.0, B)         # ... while commanded back down, some hard enough to reverse
+    table[:, 0, 0, :] = rng.uniform(-3, 3, B)
+    table[:, 1:, :, :] = rng.uniform(-1, 1, (K, 3, 2, B))
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_variant(variant)
+    sim.reset(dt, 3, x0)
+    sim.set_state(st)
+    got = sim.run_table(table)
+    c = sim.counters()
+    sim.close()
+    ref, stats = oracle_from_state(oracle, n, st, table, dt)
+    assert c["resolved"] == stats["resolved"]
+    assert 0.05 * B < stats["steps_with_events"] < 2.5 * B  # both outcomes are well represented
+    assert_same(got, ref, "grazing / reversing wall approaches")
