@@ -40,6 +40,13 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
                                            const double *__restrict__ u_all, double tau_pl, double inv_pl,
                                            double tau_pk, double inv_pk, double h) {
   const double half = h / 2.0, w = h / 6.0;
+  // Power-of-two tau_player (DIV_PLAYER_POW2, DIV_POW2_ONESTEP): k = d * 2^j with d = u - v is exact, and
+  // scaling by 2^j commutes with every rounding that follows (the magnitudes are inside the division
+  // guard's window, nothing is subnormal), so the factor moves into the step constants -- themselves
+  // exact multiples, host-checked -- and the players' four multiplications per sub-step disappear:
+  // fl(k*(h/2)) = fl(d*(2^j*h/2)), ((k1 + 2*k2) + 2*k3) + k4 = 2^j*(((d1 + 2*d2) + 2*d3) + d4) bit for bit.
+  constexpr bool FOLD = MODE == DIV_PLAYER_POW2 || MODE == DIV_POW2_ONESTEP;
+  const double half_pl = FOLD ? half * inv_pl : half, h_pl = FOLD ? h * inv_pl : h, w_pl = FOLD ? w * inv_pl : w;
   double *p = p_all + C0, *v = v_all + C0;
   const double *u = u_all + C0;
   double a[M], q[M], r[M], accv[M], accp[M];
@@ -48,6 +55,9 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #define GSIM_INV(c) ((c) + C0 >= PKC ? inv_pk : inv_pl)
 #define GSIM_COEF(c) ((c) + C0 >= PKC ? 0.2 : 1.0)
 #define GSIM_IS_PK(c) ((c) + C0 >= PKC)
+#define GSIM_HALF(c) (GSIM_IS_PK(c) ? half : half_pl)
+#define GSIM_H(c) (GSIM_IS_PK(c) ? h : h_pl)
+#define GSIM_W(c) (GSIM_IS_PK(c) ? w : w_pl)
 // numerator of f's acceleration row: players u - v (cpp:66-67); puck 0 - 0.2*v (cpp:94-95, u is always 0),
 // written as a negation: same value (only the sign of a zero can differ), and the negation is a free
 // source modifier where the subtraction from 0.0 is an instruction.
@@ -71,10 +81,10 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
   _Pragma("unroll") GSIM_EACH if (COND) q[c] = __builtin_fma(r[c], GSIM_INV(c), q[c]);
 #define GSIM_DIV()                                                                                    \
   if (MODE == DIV_POW2_ONESTEP) {                                                                     \
-    _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c] * inv_pl;                             \
+    _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c];   /* d, the 2^j is in the constants */ \
     GSIM_DIV_ONE(GSIM_IS_PK(c))                                                                       \
   } else if (MODE == DIV_PLAYER_POW2) {                                                               \
-    _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c] * inv_pl;                             \
+    _Pragma("unroll") GSIM_EACH if (!GSIM_IS_PK(c)) q[c] = a[c];                                      \
     GSIM_DIV_MARK(GSIM_IS_PK(c))                                                                      \
   } else if (MODE == DIV_MARKSTEIN) {                                                                 \
     GSIM_DIV_MARK(true)                                                                               \
@@ -89,7 +99,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
   GSIM_EACH { accv[c] = q[c]; accp[c] = v[c]; }                       // k1v, k1p
   // k2 = f(x + k1*h/2)
 #pragma unroll
-  GSIM_EACH r[c] = v[c] + q[c] * half;                                // x2v (= k2p)
+  GSIM_EACH r[c] = v[c] + q[c] * GSIM_HALF(c);                                // x2v (= k2p)
 #pragma unroll
   GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = GSIM_NUM(c, r[c]); }
   GSIM_DIV();
@@ -97,7 +107,7 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
   GSIM_EACH accv[c] = __builtin_fma(q[c], 2.0, accv[c]);
   // k3 = f(x + k2*h/2)
 #pragma unroll
-  GSIM_EACH r[c] = v[c] + q[c] * half;                                // x3v (= k3p)
+  GSIM_EACH r[c] = v[c] + q[c] * GSIM_HALF(c);                                // x3v (= k3p)
 #pragma unroll
   GSIM_EACH { accp[c] = __builtin_fma(r[c], 2.0, accp[c]); a[c] = GSIM_NUM(c, r[c]); }
   GSIM_DIV();
@@ -105,15 +115,18 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
   GSIM_EACH accv[c] = __builtin_fma(q[c], 2.0, accv[c]);
   // k4 = f(x + k3*h)
 #pragma unroll
-  GSIM_EACH r[c] = v[c] + q[c] * h;                                   // x4v (= k4p)
+  GSIM_EACH r[c] = v[c] + q[c] * GSIM_H(c);                                // x4v (= k4p)
 #pragma unroll
   GSIM_EACH { accp[c] = accp[c] + r[c]; a[c] = GSIM_NUM(c, r[c]); }
   GSIM_DIV();
 #pragma unroll
-  GSIM_EACH { p[c] = p[c] + accp[c] * w; v[c] = v[c] + (accv[c] + q[c]) * w; }   // cpp:87
+  GSIM_EACH { p[c] = p[c] + accp[c] * w; v[c] = v[c] + (accv[c] + q[c]) * GSIM_W(c); }   // cpp:87
 #undef GSIM_DIV
 #undef GSIM_DIV_MARK
 #undef GSIM_DIV_ONE
+#undef GSIM_W
+#undef GSIM_H
+#undef GSIM_HALF
 #undef GSIM_IS_PK
 #undef GSIM_NUM
 #undef GSIM_COEF

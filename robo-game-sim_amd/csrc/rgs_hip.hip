@@ -128,6 +128,13 @@ bool is_power_of_two(double tau) {
   return std::fabs(std::frexp(tau, &e)) == 0.5;
 }
 
+// x * 2^j is exact: the product is zero or a normal number and scales back to x.
+bool scales_exactly(double x, double pow2) {
+  const double y = x * pow2;
+  if (y == 0.0) return x == 0.0;
+  return std::isnormal(y) && y / pow2 == x;
+}
+
 // ---- certification of div_tau<3> (one correction step) for a given tau --------------------------
 // See gsim_common.hpp: the one-step quotient can only be wrong for dividends with significand A such
 // that |A*2^sh - M*B| <= 7 with M odd (sh = 53 for A >= B, 54 for A < B; B = tau's 53-bit significand).
@@ -361,8 +368,12 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   if (est_wave > (est_two > est_one ? est_two : est_one)) best = RGS_VARIANT_WAVE;
   const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : best);
   const bool fast = use_fast_division(s);
+  // The power-of-two modes fold 1/tau_player into the lane pass' step constants (gsim_lane.hpp): those
+  // products must be exact and normal (or zero).
+  const bool fold_ok = is_power_of_two(s->tau_player) && scales_exactly(s->dt_col / 2.0, 1.0 / s->tau_player) &&
+                       scales_exactly(s->dt_col, 1.0 / s->tau_player) && scales_exactly(s->dt_col / 6.0, 1.0 / s->tau_player);
   const int div_mode = !fast ? DIV_IEEE
-                       : (is_power_of_two(s->tau_player) ? (s->one_step_ok ? DIV_POW2_ONESTEP : DIV_PLAYER_POW2) : DIV_MARKSTEIN);
+                       : (fold_ok ? (s->one_step_ok ? DIV_POW2_ONESTEP : DIV_PLAYER_POW2) : DIV_MARKSTEIN);
   if (variant == RGS_VARIANT_HYBRID2) {
     const size_t need = gsim_ops(s->n)->vgrid_doubles(s->B);   // velocity rows of every block's grids
     if (need > s->vgrid_cap) {
