@@ -354,15 +354,22 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   // one-lane hybrid needs 65 536 arenas to put a wave on every SIMD, the two-lane hybrid 32 768; the
   // wave-per-arena kernel spreads even a few hundred arenas over the whole chip (one wave each) and is
   // 2-4x faster than either hybrid below ~8k arenas (1024 x 2v2: 5.2e7 vs 2.4e7), modelled as
-  // B / (t0 + B / saturated rate).  Examples: 65 536 x 4v4 one-lane 5.2e8 (two-lane 4.6e8); C5,
-  // 32 768 x 4v4, two-lane 2.7e8 (one-lane 1.5e8); the drop-in GameSim (1 arena) uses the wave kernel.
-  static const double rate_one[8] = {0, 1390, 1000, 680, 520, 340, 210, 92};
-  static const double rate_two[8] = {0, 800, 650, 480, 460, 314, 241, 184};
+  // B / (t0 + B / saturated rate).  Examples: 65 536 x 4v4 one-lane 5.0e8 (two-lane 4.9e8); C5,
+  // 32 768 x 4v4, two-lane 2.8e8 (one-lane 1.5e8); the drop-in GameSim (1 arena) uses the wave kernel.
+  // hybrids: measured at 32 768 and 65 536 arenas (tools/sweep.sh, profiles/r01/sweep_team_size.json), linear in
+  // between and below, flat above
+  static const double one32[8] = {0, 622, 595, 368, 241, 163, 98, 68}, one65[8] = {0, 1442, 1072, 721, 503, 314, 188, 131};
+  static const double two32[8] = {0, 681, 780, 503, 439, 293, 235, 189}, two65[8] = {0, 1387, 810, 593, 488, 324, 247, 197};
   static const double wave_sat[8] = {0, 320, 280, 230, 186, 130, 90, 62};
   static const double wave_t0_us[8] = {0, 13, 13, 13, 12, 12, 11, 10};
   const double Bd = (double)s->B;
-  const double est_one = rate_one[s->n] * (Bd >= 65536.0 ? 1.0 : Bd / 65536.0);
-  const double est_two = rate_two[s->n] * (Bd >= 32768.0 ? 1.0 : Bd / 32768.0);
+  auto hybrid_rate = [Bd](double r32, double r65) {
+    if (Bd <= 32768.0) return r32 * Bd / 32768.0;
+    if (Bd >= 65536.0) return r65;
+    return r32 + (r65 - r32) * (Bd - 32768.0) / 32768.0;
+  };
+  const double est_one = hybrid_rate(one32[s->n], one65[s->n]);
+  const double est_two = hybrid_rate(two32[s->n], two65[s->n]);
   const double est_wave = Bd / (wave_t0_us[s->n] + Bd / wave_sat[s->n]);
   int best = est_two > est_one ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID;
   if (est_wave > (est_two > est_one ? est_two : est_one)) best = RGS_VARIANT_WAVE;
