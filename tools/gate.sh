@@ -1,3 +1,5 @@
+# Round gate on the GPU box: GPU tests, smoke, every bench config (C2 with ALL arenas checked against the
+# oracle), a 2-rank rehearsal of the multi-GPU path on the one GPU.  Outputs under gpurun_out/gate/.
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/gate
@@ -6,8 +8,10 @@ tail -3 gpurun_out/gate/pytest.log
 timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/gate/smoke.log 2>&1 || { tail -20 gpurun_out/gate/smoke.log; exit 1; }
 tail -1 gpurun_out/gate/smoke.log
 for c in c2 c3 c4 c5; do timeout -k 10 400 python bench.py --config $c > gpurun_out/gate/bench_$c.json; done
+timeout -k 10 600 python bench.py --cpu-sample-arenas 65536 > gpurun_out/gate/bench_c2_all_arenas.json
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 200 --backend gloo --force-device 0 > gpurun_out/gate/bench_2rank_rehearsal.json 2> gpurun_out/gate/bench_2rank_rehearsal.err
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/gate/bench_*.json')):
-    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, '%.4g'%d['value'], d['events'].get('flagged'), d.get('parity'), d['cpu_baseline']['value'])
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, '%.4g'%d['value'], d['n_gpus'], d['events'].get('flagged'), d.get('parity'), (d.get('cpu_baseline') or {}).get('value'))
 PY
