@@ -287,7 +287,7 @@ int noise_step(rgs_sim *s, StepArgs a) {
 
 int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps, double *traj = nullptr,
                  int traj_every = 0) {
-  StepArgs a;
+  StepArgs a{};
   a.dt = s->dt; a.dt_col = s->dt_col;
   a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
   a.inv_tau_player = 1.0 / s->tau_player; a.inv_tau_puck = 1.0 / s->tau_puck;   // host IEEE division

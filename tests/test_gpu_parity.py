@@ -629,3 +629,18 @@ def test_wall_watch_at_grazing_and_reversing_approaches(rgp, oracle, variant, dt
     assert c["resolved"] == stats["resolved"]
     assert 0.05 * B < stats["steps_with_events"] < 2.5 * B  # both outcomes are well represented
     assert_same(got, ref, "grazing / reversing wall approaches")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("tau_player,dt", [(0.25, 0.01), (2.0, 0.03), (0.0625, 0.005), (0.5, 0.037)])
+def test_power_of_two_tau_folded_into_step_constants(rgp, oracle, tau_player, dt, variant):
+    """With tau_player = 2^j the lane pass never divides or multiplies by it: the factor lives in the RK4
+    step constants (gsim_lane.hpp, rk4_chains).  Other powers of two than the default 0.5, and step
+    sizes whose thirds and sixths are not round numbers, against the oracle's plain divisions."""
+    from robo_game_py import workloads as w
+    n, B, K = 2, 512, 150
+    x0, amp, ph = w.c2_inputs(B, n, seed=31)
+    table = w.circle_controls(amp * 1.5, ph, w.step_times(K, dt))
+    out, ref = run_both(rgp, oracle, n, x0, table, dt, variant=variant, tau_player=tau_player)
+    check(out, ref, "tau_player=%g dt=%g" % (tau_player, dt))
