@@ -258,7 +258,9 @@ def main():
             valu_issue = {"achieved": round(per_wave_step * wave_steps_per_s / 1e9, 2), "peak": round(peak / 1e9, 1),
                           "unit": "G wave-instr/s", "frac": round(per_wave_step * wave_steps_per_s / peak, 4),
                           "valu_wave_instr_per_wave_step": round(per_wave_step, 1),
-                          "source": "SQ_INSTS_VALU from profiles/r01/hybrid_pmc.json (not collected live)"}
+                          "source": "SQ_INSTS_VALU from profiles/r01/hybrid_pmc.json (not collected live)",
+                          "note": "peak = one wave64 instruction per 4 cycles per SIMD; a lone wave per SIMD issues FP64 "
+                                  "every 5.2-5.8 cycles (profiles/r01/fp64_issue_rate.txt)"}
     except Exception:
         valu_issue = None
     model_tflops = model_flops_per_arena_step(n) * B * K / (kernel_ms * 1e-3) / 1e12

@@ -31,8 +31,10 @@ enum DivMode : int { DIV_IEEE = 0, DIV_MARKSTEIN = 1, DIV_PLAYER_POW2 = 2, DIV_P
 
 // One RK4 sub-step for M independent chains, written stage-major: every statement below is a
 // loop over the chains, so consecutive instructions belong to different chains and a single
-// wave per SIMD (65 536 arenas = 1024 waves = one per SIMD) still issues back to back instead
-// of waiting out each dependent fp64 latency.  Arithmetic per chain is exactly rk4_axis<DM>.
+// wave per SIMD (65 536 arenas = 1024 waves = one per SIMD) issues at its ~5.2 cycles per FP64
+// instruction instead of waiting 8 on each dependent one (tools/ubench/fp64rate.hip).  The compiler's
+// default scheduler undoes the interleaving; the 1v1/2v2 objects are built with max-ilp (Makefile).
+// Arithmetic per chain is exactly rk4_axis<DM>.
 
 // The batch is chains [C0, C0 + M) of the arena's arrays; chains >= PKC belong to the puck.
 template <int MODE, int C0, int M, int PKC>
