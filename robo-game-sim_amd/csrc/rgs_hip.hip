@@ -89,7 +89,7 @@ struct rgs_sim {
   // AUTO variant: contact regime estimate (see launch_steps)
   bool auto_wave = false;          // currently preferring the wave-per-arena kernel
   long long window_steps = 0;      // steps launched since the last look at the counters
-  unsigned long long seen_busy = 0;  // flagged + event_steps at that look
+  unsigned long long seen_busy = 0;  // events resolved at that look
   bool one_step_enabled = true;    // rgs_set_fast_division(2) = allow, (1) = two steps only
   // noise > 0: the reference's generator per arena, src/GameSim.cpp:3,41 -- the engine is
   // re-seeded by reset(), the distribution (with its cached second draw) deliberately is not.
@@ -330,23 +330,24 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     }
     return RGS_OK;
   }
-  // Both hybrids assume that flagged arenas are the exception.  In sustained contact (most arenas
-  // flagged every step, many 49-event steps) the plain wave-per-arena kernel, with four waves per SIMD
-  // to hide its latency, is faster (measured crossover near 10 % flagged: 76 % flagged 3.4e7 vs 1.9e7).
-  // So every >= 64 launched steps AUTO looks at the counters of the finished launches and switches
-  // with hysteresis (> 15 % busy arena-steps -> wave kernel, < 8 % -> hybrid).  Results are identical
-  // either way; only this host-side choice depends on the history.
+  // Both hybrids assume that events are the exception.  They stay ahead of the plain wave-per-arena
+  // kernel far into contact-rich play (2v2, random commands up to 100: 74 % of the arena-steps have an
+  // event and the one-lane hybrid still does 8.5e7 against 4.7e7; 4v4 two-lane: level at 79 %), but not
+  // when every step resolves a chain of events (everybody jammed together, 3-13 events per arena-step, 49-event
+  // cap hits: wave kernel 4.4e7, hybrids 4.0e7 / 3.7e7 averaged over the build-up and further apart later):
+  // there the wave kernel's four waves per SIMD hide the serial event chains.  So every >= 64 launched
+  // steps AUTO looks at the events resolved per arena-step in the finished launches and switches with
+  // hysteresis (> 3 -> wave kernel, < 2 -> hybrid).  Results are identical either way; only this
+  // host-side choice depends on the history.
   if (s->variant == RGS_VARIANT_AUTO && s->window_steps >= 64) {
     unsigned long long c[CNT_N];
     HIP_TRY(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    const unsigned long long busy = s->auto_wave ? c[CNT_EVENT_STEPS] : c[CNT_FLAGGED];
-    const unsigned long long both = c[CNT_EVENT_STEPS] + c[CNT_FLAGGED];   // monotone across switches
-    const double ratio = (double)(both - s->seen_busy) / ((double)s->window_steps * (double)s->B);
-    (void)busy;
-    if (!s->auto_wave && ratio > 0.15) s->auto_wave = true;
-    else if (s->auto_wave && ratio < 0.08) s->auto_wave = false;
-    s->seen_busy = both;
+    const unsigned long long resolved = c[CNT_RESOLVED];     // counted alike by every kernel
+    const double per_step = (double)(resolved - s->seen_busy) / ((double)s->window_steps * (double)s->B);
+    if (!s->auto_wave && per_step > 3.0) s->auto_wave = true;
+    else if (s->auto_wave && per_step < 2.0) s->auto_wave = false;
+    s->seen_busy = resolved;
     s->window_steps = 0;
   }
   if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
