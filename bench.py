@@ -179,6 +179,8 @@ def main():
     # ---- warm-up, then the timed region ----------------------------------------------------
     run_steps(0, W)
     barrier()
+    if args.stamps:
+        sim.stamps(True, clear=True)                 # the timed launches only
     t0 = time.perf_counter()
     sim.timer_start()
     launches = run_steps(W, K)

@@ -135,12 +135,14 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * RGS_VARIANT_AUTO currently prefers the wave-per-arena kernel (sustained-contact regime), else 0. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
-/* Diagnostic in-kernel stamps (s_memtime) of the one-lane hybrid kernel; only in a library built with
- * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable
- * applies to later launches; out9 (may be NULL) receives 9 totals since the last reset, summed over
- * waves: lane-pass cycles, wave-pass cycles, wave-pass rounds, whole-kernel cycles, then for lane
- * group 0 of every wave pass: fill, first-scan, event-loop, commit cycles and the arena count. */
-int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out9);
+/* Diagnostic in-kernel stamps (s_memtime) of the hybrid kernels; only in a library built with
+ * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable: bit 0 = stamps on
+ * for later launches, bit 1 = clear the totals first.  out13 (may be NULL) receives 13 values since the
+ * last reset/clear.  Summed over waves: lane-pass cycles, wave-pass cycles, wave-pass rounds,
+ * whole-kernel cycles; for lane group 0 of every wave pass: fill, first-scan, event-loop, commit cycles
+ * and the arena count; maxima over waves: whole-kernel cycles, wave-pass cycles, rounds, and the longest
+ * single event loop. */
+int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out13);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
 

@@ -56,7 +56,9 @@ enum Counter : int {
   CNT_N = 8,
   // diagnostic stamps (StepArgs::stamps != 0): summed over waves, shader cycles
   STAMP_LANE = 0, STAMP_WAVE = 1, STAMP_ROUNDS = 2, STAMP_TOTAL = 3,
-  STAMP_FILL = 4, STAMP_SCAN0 = 5, STAMP_EVENTS = 6, STAMP_COMMIT = 7, STAMP_ARENAS = 8, STAMP_N = 9
+  STAMP_FILL = 4, STAMP_SCAN0 = 5, STAMP_EVENTS = 6, STAMP_COMMIT = 7, STAMP_ARENAS = 8,
+  // maxima over waves (atomicMax): whole kernel, wave-pass cycles, rounds; and the longest single event loop
+  STAMP_MAX_TOTAL = 9, STAMP_MAX_WAVE = 10, STAMP_MAX_ROUNDS = 11, STAMP_MAX_EVENTS = 12, STAMP_N = 13
 };
 
 // Everything one launch needs.  Arrays are SoA with the arena index fastest.
@@ -69,6 +71,13 @@ struct StepArgs {
   //   le = max{s : fl(sqrt(s)) <= R}   so  fl(sqrt(s)) <= R   <=>  s <= le   (cpp:471)
   //   lt = max{s : fl(sqrt(s)) <  R}   so  R - fl(sqrt(s)) > 0 <=>  s <= lt   (cpp:260-261, 584-585)
   double le_pp, le_pk, lt_pp, lt_pk;
+  // Quotients the carry-out needs for every event, host-computed with IEEE '/' (same value as the
+  // reference's run-time division).  Overlap push ((c*r_own)/(ri+rj)), c = 1.01 (cpp:263-264) and
+  // c = 1.1 (OVERLAP_BUFFER, cpp:588-589): _pp own and other are players; _plk own = player, other = puck;
+  // _pkk own = puck.  Impulse factor (2*m_other)/(mi+mj) (cpp:273-274): _pp; _vs_puck (own = player,
+  // other = puck); _vs_player (own = puck).
+  double push101_pp, push101_plk, push101_pkk, push11_pp, push11_plk, push11_pkk;
+  double ratio_pp, ratio_vs_puck, ratio_vs_player;
   double win;                        // winning_score_ as a double (scores are doubles, SimState.h:25)
   long long B;                       // arenas
   double *state;                     // [S][B]

@@ -101,7 +101,11 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
     atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
     atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
     atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
-    atomicAdd(&p.stamp_out[STAMP_TOTAL], __builtin_amdgcn_s_memtime() - t_begin);
+    const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
+    atomicAdd(&p.stamp_out[STAMP_TOTAL], t_all);
+    atomicMax(&p.stamp_out[STAMP_MAX_TOTAL], t_all);
+    atomicMax(&p.stamp_out[STAMP_MAX_WAVE], t_wave);
+    atomicMax(&p.stamp_out[STAMP_MAX_ROUNDS], n_rounds);
   }
 }
 
@@ -164,7 +168,11 @@ __global__ __launch_bounds__(64, GSIM_H2_WAVES) void k_step_hybrid2(StepArgs p) 
     atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
     atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
     atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
-    atomicAdd(&p.stamp_out[STAMP_TOTAL], __builtin_amdgcn_s_memtime() - t_begin);
+    const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
+    atomicAdd(&p.stamp_out[STAMP_TOTAL], t_all);
+    atomicMax(&p.stamp_out[STAMP_MAX_TOTAL], t_all);
+    atomicMax(&p.stamp_out[STAMP_MAX_WAVE], t_wave);
+    atomicMax(&p.stamp_out[STAMP_MAX_ROUNDS], n_rounds);
   }
 }
 

@@ -258,6 +258,133 @@ struct EventSlots {
   }
 };
 
+// This lane's part in carrying out one event (lanes 0..3 of the group): which (disc, axis) chain it
+// integrates and the correction rule of the re-integrated columns.  Lanes 0,1 carry disc i (x, y);
+// lanes 2,3 carry disc j of a pair event and a harmless duplicate of disc i for a wall event.
+template <int N>
+struct EventLane {
+  int d, ax;
+  bool first, is_pair, my_axis, positive_wall, store;
+  double u, coef, tau, inv, r_own, rsum, lt, wall;
+  double push101, push11;    // ((1.01*r_own)/(ri+rj)), ((1.1*r_own)/(ri+rj)): cpp:263-264, 588-589 (host-computed quotients)
+  double mass_ratio;         // (2*m_other)/(mi+mj), cpp:273-274
+};
+
+template <int N, bool SPLITV>
+__device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const GridView<N, SPLITV> &G, int ci, int cj, int kind,
+                                                   int lg) {
+  constexpr int PK = 2 * N;
+  EventLane<N> c;
+  c.is_pair = kind == PAIR;
+  c.first = (lg & 2) == 0;
+  c.ax = lg & 1;
+  c.d = (c.is_pair && !c.first) ? cj : ci;
+  c.store = c.is_pair || c.first;
+  c.r_own = disc_radius<N>(c.d);
+  c.u = G.ctl(c.d, c.ax);
+  c.coef = c.d == PK ? 0.2 : 1.0;
+  c.tau = c.d == PK ? p.tau_puck : p.tau_player;
+  c.inv = c.d == PK ? p.inv_tau_puck : p.inv_tau_player;
+  const bool with_puck = ci == PK || cj == PK;
+  c.rsum = disc_radius<N>(ci) + disc_radius<N>(c.is_pair ? cj : ci);
+  c.lt = with_puck ? p.lt_pk : p.lt_pp;                      // s <= lt  <=>  rsum - sqrt(s) > 0
+  c.push101 = !with_puck ? p.push101_pp : (c.d == PK ? p.push101_pkk : p.push101_plk);
+  c.push11 = !with_puck ? p.push11_pp : (c.d == PK ? p.push11_pkk : p.push11_plk);
+  c.mass_ratio = !with_puck ? p.ratio_pp : (c.d == PK ? p.ratio_vs_player : p.ratio_vs_puck);
+  c.my_axis = (kind == UP || kind == DOWN) ? (c.ax == 1) : (c.ax == 0);
+  c.positive_wall = (kind == UP || kind == RIGHT);
+  c.wall = (kind == UP || kind == DOWN) ? kY / 2.0 : kX / 2.0;
+  return c;
+}
+
+// correctOverlap of one re-integrated column (pair: cpp:581-592, wall: cpp:594-623), then the store
+// into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).
+template <int N, bool SPLITV>
+__device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
+                                                 bool wall_fix) {
+  if (c.is_pair) {
+    const double po = quad_xor2(x.p);
+    const double pij = c.first ? po - x.p : x.p - po;
+    const double sq = pij * pij;
+    const double s = sq + quad_xor1(sq);
+    if (s <= c.lt) {
+      const double overlap = c.rsum - sqrt_ieee(s);
+      const double cc = c.push11 * overlap;
+      x.p = c.first ? x.p - cc * pij : x.p + cc * pij;
+    }
+  } else if (c.my_axis && wall_fix) {
+    const double overlap = c.positive_wall ? (x.p + c.r_own - c.wall) : (-x.p + c.r_own - c.wall);
+    if (overlap > 0) {
+      const double cc = 1.1 * overlap;
+      x.p = c.positive_wall ? x.p - cc : x.p + cc;
+    }
+  }
+  if (c.store) {
+    G.pos(g, c.d, c.ax) = x.p;
+    G.vel(g, c.d, c.ax) = x.v;
+  }
+}
+
+// Completes columns from..to of a pending event's discs (see arena_step_group): continues from grid
+// column from-1 under that event's correction rule, exactly the reference's loop cpp:292-297 / 336-340.
+template <int N, int FAST, bool SPLITV>
+__device__ __forceinline__ void finish_columns(const StepArgs &p, const GridView<N, SPLITV> &G, int ci, int cj, int kind,
+                                               int from, int to, double dt_col, int lg) {
+  if (lg < 4) {
+    const EventLane<N> c = event_lane<N, SPLITV>(p, G, ci, cj, kind, lg);
+    Chain x;
+    x.p = G.pos(from - 1, c.d, c.ax);
+    x.v = G.vel(from - 1, c.d, c.ax);
+    const bool fast = FAST != 0 && fast_division_safe(c.u, x.v);
+    for (int g = from; g <= to; ++g) {
+      x = rk4_dyn<FAST>(x, c.u, c.coef, c.tau, c.inv, dt_col, fast);
+      fix_store_column<N, SPLITV>(c, G, x, g, true);
+    }
+  }
+  grid_sync<SPLITV>();
+}
+
+// insertCollisions' inner loops (cpp:365-506) for the discs of a carried-out event over grid columns
+// lo..hi: the first column whose best candidate satisfies t_col - t_ < dt_, per disc.  A pair's two
+// scans run side by side (lanes [0, GW/2) <-> columns of disc i, lanes [GW/2, GW) <-> disc j): they
+// only read the grid, so their order does not matter.  done_*: nothing (more) to look for; found_* and
+// the event fields are set when a hit is found.  Group-uniform results.
+template <int N, int GW, bool SPLITV>
+__device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N, SPLITV> &G, int ci, int cj, int lo, int hi,
+                                             double t0, double dt, double dt_col, int lg, int gbase, bool &done_i,
+                                             bool &done_j, bool &found_i, bool &found_j, double &ti, int &ji, int &ki,
+                                             double &tj, int &jj, int &kj) {
+  const bool two = cj >= 0;
+  const int H = two ? GW / 2 : GW;
+  const int which = (two && lg >= H) ? 1 : 0;
+  const int l = which ? lg - H : lg;
+  const int id = which ? cj : ci;
+  for (int g0 = lo; g0 <= hi && !(done_i && done_j); g0 += H) {
+    const int g = g0 + l;
+    const bool want = which ? !done_j : !done_i;
+    bool hit = false;
+    double bt = 1.0e9;
+    int bj = -1, bk = -1;
+    if (g <= hi && want) {
+      column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, ~0u, bt, bj, bk);
+      hit = (bt - t0 < dt);                                  // cpp:501
+    }
+    const unsigned long long m = group_ballot<GW>(hit, gbase);
+    const unsigned long long mi = two ? (m & ((1ull << (GW / 2)) - 1ull)) : m;
+    const unsigned long long mj = two ? (m >> (GW / 2)) : 0ull;
+    if (!done_i && mi != 0ull) {
+      const int src = gbase + __builtin_ctzll(mi);
+      ti = __shfl(bt, src); ji = __shfl(bj, src); ki = __shfl(bk, src);
+      done_i = true; found_i = true;
+    }
+    if (!done_j && mj != 0ull) {
+      const int src = gbase + GW / 2 + __builtin_ctzll(mj);
+      tj = __shfl(bt, src); jj = __shfl(bj, src); kj = __shfl(bk, src);
+      done_j = true; found_j = true;
+    }
+  }
+}
+
 // Full reference step for arena `a`.  G: this group's LDS region (WaveLayout<N>::DOUBLES).
 // lg: lane index inside the group; gbase: wave lane of the group's lane 0.
 // discmask: bits 0..E-1 = discs whose overlap watch fired in the lane pass (all ones when unknown) --
@@ -363,67 +490,85 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   const bool had_events = ev.any();
   if (stamp) ts2 = __builtin_amdgcn_s_memtime();
 
+  // Lazily re-integrated columns.  The reference re-integrates the colliding discs over ALL remaining
+  // columns base..50 (cpp:285-297, 330-340) and only then re-scans them from column base (cpp:147).  When
+  // discs stay in contact the re-scan finds the next event in column base itself, and that event
+  // re-integrates the same discs from there again: the 49 events of a step that runs into the iteration
+  // cap (a puck spawned inside a player, C2: 4.5 % of the arenas in their first step) recompute ~2400
+  // columns of which ~100 are ever read.  Here the columns are produced in growing chunks (1, 3, then
+  // half a group's width), each chunk scanned as soon as it exists -- lanes of the lower half of the
+  // group take disc i's columns, the upper half disc j's; the two scans are independent of each other
+  // since neither writes the grid -- and production stops once both discs have their event.  What is
+  // left (columns vu+1..50 of the "pending" discs, to be continued from grid column vu under the
+  // pending event's correction rule) is only computed if somebody can read it:
+  //   * the next carried-out event involves exactly the pending discs: it restarts them from its own
+  //     column base-1 (>= the pending event's base, event times never move back past a carried-out
+  //     column), so only columns up to base-1 are completed and the rest is dropped unread;
+  //   * any other carried-out event, and the end of the loop: the pending discs are completed to
+  //     column 50 first, which leaves the grid exactly as the reference has it at that point.
+  // Between a carried-out event and the next one nothing but the re-scans of i and j reads the grid
+  // (skipped puck events, cpp:230-231, read nothing), so every value read is the value the reference
+  // reads.  With noise the draws are bound to the RK4 call order and the whole remainder is produced
+  // at once (one chunk).
+  int pend_i = -1, pend_j = -1, pend_kind = -1, vu = kGrid;   // group-uniform
+
   while (ev.any() && counter < kLoopCap) {
     int ci, cj, ckind;
     double ct;
     ev.pop(ci, ct, cj, ckind);                               // cpp:227
     counter++;
     if ((ci == PK || cj == PK) && scored) { n_skipped++; continue; }   // cpp:230-231
+    const bool is_pair = ckind == PAIR;
+    if (!NOISE && pend_i >= 0) {
+      const bool same = is_pair ? (pend_kind == PAIR && ((ci == pend_i && cj == pend_j) || (ci == pend_j && cj == pend_i)))
+                                : (pend_kind != PAIR && ci == pend_i);
+      if (!same) {
+        finish_columns<N, FAST, SPLITV>(p, G, pend_i, pend_j, pend_kind, vu + 1, kGrid, dt_col, lg);
+        pend_i = -1; vu = kGrid;
+      }
+    }
     base = (int)__builtin_floor(div_ieee(ct - t0, dt_col)) + 1;        // cpp:237
     if (base > kGrid) { base = kGrid; n_overflow++; }        // reference: out-of-bounds column
     if (base < 1) base = 1;
     n_resolved++;
+    if (!NOISE && pend_i >= 0 && base - 1 > vu) {            // the new event starts from a column not produced yet
+      finish_columns<N, FAST, SPLITV>(p, G, pend_i, pend_j, pend_kind, vu + 1, base - 1, dt_col, lg);
+      vu = base - 1;
+    }
     const double dt_t = ct - (t0 + dt_col * (double)(base - 1));       // cpp:254,308
-    const bool is_pair = ckind == PAIR;
 
     // Lanes 0,1 carry disc i (x, y); lanes 2,3 carry disc j for a pair event and a harmless
     // duplicate of disc i for a wall event, so both kinds share one instruction stream.
-    bool goal = false;
+    const EventLane<N> el = event_lane<N, SPLITV>(p, G, ci, cj, ckind, lg);
+    Chain x{0.0, 0.0};
+    bool fast = false, goal = false;
+    // noise bookkeeping: np players among the event's discs draw; this lane's disc is the slot-th of them
+    const int np = NOISE ? ((ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0)) : 0;
+    const int slot = (is_pair && !el.first && ci != PK) ? 1 : 0;
+    const double sg = (NOISE && el.d != PK) ? p.sigma : 0.0;
+    int call = 0;                                            // this disc's RK4 calls so far in this event
+    auto noisy = [&](Chain xx, double hh) {
+      const int c0 = cur + 8 * (call * np + slot);
+      ++call;
+      return rk4_axis_noise(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax);
+    };
     if (lg < 4) {
-      const bool first = lg < 2;
-      const int d = (is_pair && !first) ? cj : ci, ax = lg & 1;
-      const double r_own = disc_radius<N>(d);
-      const double u = G.ctl(d, ax);
-      const double coef = d == PK ? 0.2 : 1.0, tau = d == PK ? p.tau_puck : p.tau_player;
-      const double inv = d == PK ? p.inv_tau_puck : p.inv_tau_player;
-      Chain x;
-      x.p = G.pos(base - 1, d, ax);
-      x.v = G.vel(base - 1, d, ax);
-      bool fast = FAST != 0 && fast_division_safe(u, x.v);
-      // noise bookkeeping: np players among the event's discs draw; this lane's disc is the slot-th of them
-      const int np = NOISE ? ((ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0)) : 0;
-      const int slot = (is_pair && !first && ci != PK) ? 1 : 0;
-      const double sg = (NOISE && d != PK) ? p.sigma : 0.0;
-      int call = 0;                                          // this disc's RK4 calls so far in this event
-      auto noisy = [&](Chain xx, double hh) {
-        const int c0 = cur + 8 * (call * np + slot);
-        ++call;
-        return rk4_axis_noise(xx, u, coef, tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + ax);
-      };
+      x.p = G.pos(base - 1, el.d, el.ax);
+      x.v = G.vel(base - 1, el.d, el.ax);
+      fast = FAST != 0 && fast_division_safe(el.u, x.v);
       if (NOISE) x = noisy(x, dt_t); else
-      x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_t, fast);   // cpp:255-256, 309
-
-      // pair constants (unused for walls)
-      const double rsum = disc_radius<N>(ci) + disc_radius<N>(is_pair ? cj : ci);
-      const double lt = (ci == PK || cj == PK) ? p.lt_pk : p.lt_pp;   // s <= lt  <=>  rsum - sqrt(s) > 0
-      // wall constants (unused for pairs)
-      const bool my_axis = (ckind == UP || ckind == DOWN) ? (ax == 1) : (ax == 0);
-      const bool positive_wall = (ckind == UP || ckind == RIGHT);
-      const double wall = (ckind == UP || ckind == DOWN) ? kY / 2.0 : kX / 2.0;
+      x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_t, fast);   // cpp:255-256, 309
 
       if (is_pair) {                                         // cpp:242-282
-        const int o = first ? cj : ci;
-        const double m_i = ci == PK ? p.m_puck : p.m_player, m_j = cj == PK ? p.m_puck : p.m_player;
-        const double m_oth = o == PK ? p.m_puck : p.m_player;
         {                                                    // cpp:259-265 (pij not normalised)
           const double po = quad_xor2(x.p);
-          const double pij = first ? po - x.p : x.p - po;
+          const double pij = el.first ? po - x.p : x.p - po;
           const double sq = pij * pij;
           const double s = sq + quad_xor1(sq);
-          if (s <= lt) {
-            const double overlap = rsum - sqrt_ieee(s);
-            const double c = div_ieee(1.01 * r_own, rsum) * overlap;
-            x.p = first ? x.p - c * pij : x.p + c * pij;
+          if (s <= el.lt) {
+            const double overlap = el.rsum - sqrt_ieee(s);
+            const double c = el.push101 * overlap;           // ((1.01*r)/(ri+rj))*overlap
+            x.p = el.first ? x.p - c * pij : x.p + c * pij;
           }
         }
         {                                                    // elastic impulse, cpp:268-274
@@ -432,66 +577,36 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           const double pr = dv * dp, sq = dp * dp;
           const double dot1 = pr + quad_xor1(pr);
           const double dot2 = sq + quad_xor1(sq);
-          const double s = div_ieee(div_ieee(2 * m_oth, m_i + m_j) * dot1, dot2);
+          const double s = div_ieee(el.mass_ratio * dot1, dot2);   // ((2*m_other)/(mi+mj))*dot1/dot2
           if (ci != PK && cj != PK) {                        // damage, cpp:277-282
             const double dvsq = dv * dv;
             const double dv_sq = 0.01 * (dvsq + quad_xor1(dvsq));
             if (lg == 0) {
               constexpr int Pn = L::P;
-              p.damage[(long long)(ci * Pn + cj) * B + a] += m_i * dv_sq;
-              p.damage[(long long)(cj * Pn + ci) * B + a] += m_j * dv_sq;
+              p.damage[(long long)(ci * Pn + cj) * B + a] += p.m_player * dv_sq;
+              p.damage[(long long)(cj * Pn + ci) * B + a] += p.m_player * dv_sq;
             }
           }
           x.v = x.v - s * dp;
         }
       } else {                                               // wall, cpp:300-327
-        if (my_axis) {                                       // cpp:314-317
-          if (positive_wall ? (x.v > 0) : (x.v < 0)) x.v *= -1.0;
+        if (el.my_axis) {                                    // cpp:314-317
+          if (el.positive_wall ? (x.v > 0) : (x.v < 0)) x.v *= -1.0;
         }
         const double py = quad_lane1(x.p);
-        goal = d == PK && (ckind == LEFT || ckind == RIGHT) && py < kGoalH / 2.0 && py > -kGoalH / 2.0;  // cpp:321-322
+        goal = el.d == PK && (ckind == LEFT || ckind == RIGHT) && py < kGoalH / 2.0 && py > -kGoalH / 2.0;  // cpp:321-322
       }
-      fast = FAST != 0 && fast_division_safe(u, x.v);        // the velocity just changed
+      fast = FAST != 0 && fast_division_safe(el.u, x.v);     // the velocity just changed
       if (goal) {
         x.p = 0.0; x.v = 0.0;                                // cpp:325
       } else if (NOISE) {
         x = noisy(x, dt_col - dt_t);
       } else {
-        x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col - dt_t, fast);   // cpp:287-288, 331
+        x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col - dt_t, fast);   // cpp:287-288, 331
       }
-      for (int g = base; g <= kGrid; ++g) {
-        if (g > base) {
-          if (NOISE) x = noisy(x, dt_col); else
-          x = rk4_dyn<FAST>(x, u, coef, tau, inv, dt_col, fast);   // cpp:294-295, 338
-        }
-        if (is_pair) {                                       // correctOverlap(i, j), cpp:581-592
-          const double po = quad_xor2(x.p);
-          const double pij = first ? po - x.p : x.p - po;
-          const double sq = pij * pij;
-          const double s = sq + quad_xor1(sq);
-          if (s <= lt) {
-            const double overlap = rsum - sqrt_ieee(s);
-            const double c = div_ieee(1.1 * r_own, rsum) * overlap;
-            x.p = first ? x.p - c * pij : x.p + c * pij;
-          }
-        } else if (my_axis && !(goal && g == base)) {        // correctOverlap(wall), cpp:594-623
-          const double overlap = positive_wall ? (x.p + r_own - wall) : (-x.p + r_own - wall);
-          if (overlap > 0) {
-            const double c = 1.1 * overlap;
-            x.p = positive_wall ? x.p - c : x.p + c;
-          }
-        }
-        if (is_pair || first) {
-          G.pos(g, d, ax) = x.p;
-          G.vel(g, d, ax) = x.v;
-        }
-      }
+      fix_store_column<N, SPLITV>(el, G, x, base, !goal);    // cpp:289, 332 (no wall push after a goal, cpp:324-327)
     }
     goal = __shfl(goal ? 1 : 0, gbase) != 0;
-    if (NOISE) {                                             // calls per drawing disc: impact, remainder (not after a goal), columns
-      const int np_ev = (ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0);
-      cur += 8 * np_ev * ((goal ? 1 : 2) + (kGrid - base));
-    }
     if (goal) {                                              // cpp:324-326
       if (!scored) { if (ckind == RIGHT) TAS += 1.0; else TBS += 1.0; }
       scored = true;
@@ -499,13 +614,47 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     grid_sync<SPLITV>();
 
     ev.purge(ci, cj);                                        // cpp:347-352
-    {                                                        // re-scan i_ then j_, cpp:355-357 -> 147
-      double tt; int jj, kk;
-      if (scan_disc<N, GW, SPLITV>(p, G, ci, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk)) ev.put(ci, tt, jj, kk, seq++);
-      if (cj >= 0 && scan_disc<N, GW, SPLITV>(p, G, cj, base, t0, dt, dt_col, lg, gbase, ~0u, tt, jj, kk))
-        ev.put(cj, tt, jj, kk, seq++);
+    // re-scan i_ then j_ (cpp:355-357 -> 147) over the columns as they are produced
+    bool done_i = false, done_j = cj < 0, found_i = false, found_j = false;
+    double ti = 0.0, tj = 0.0;
+    int ji = -1, ki = -1, jj = -1, kj = -1;
+    constexpr int H2 = GW / 2;
+    int lo = base, hi = NOISE ? kGrid : base;
+    if (NOISE && base < kGrid) {                             // noise: the whole remainder in the reference's call order
+      if (lg < 4) {
+        for (int g = base + 1; g <= kGrid; ++g) {
+          x = noisy(x, dt_col);                              // cpp:294-295, 338
+          fix_store_column<N, SPLITV>(el, G, x, g, true);
+        }
+      }
+      grid_sync<SPLITV>();
     }
+    if (NOISE) {                                             // calls per drawing disc: impact, remainder (not after a goal), columns
+      const int np_ev = (ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0);
+      cur += 8 * np_ev * ((goal ? 1 : 2) + (kGrid - base));
+    }
+    for (int chunk = 0;; ++chunk) {
+      scan_columns<N, GW, SPLITV>(p, G, ci, cj, lo, hi, t0, dt, dt_col, lg, gbase, done_i, done_j, found_i, found_j, ti, ji,
+                                  ki, tj, jj, kj);
+      if ((done_i && done_j) || hi >= kGrid) break;
+      lo = hi + 1;
+      const int width = chunk == 0 ? 3 : (cj < 0 ? GW : H2);
+      hi = lo + width - 1 < kGrid ? lo + width - 1 : kGrid;
+      if (lg < 4) {
+        for (int g = lo; g <= hi; ++g) {
+          x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col, fast);   // cpp:294-295, 338
+          fix_store_column<N, SPLITV>(el, G, x, g, true);
+        }
+      }
+      grid_sync<SPLITV>();
+    }
+    vu = hi;
+    if (vu < kGrid) { pend_i = ci; pend_j = cj; pend_kind = ckind; } else pend_i = -1;
+    if (found_i) ev.put(ci, ti, ji, ki, seq++);
+    if (found_j) ev.put(cj, tj, jj, kj, seq++);
   }
+  if (!NOISE && pend_i >= 0)                                 // whatever is still pending is part of the final grid
+    finish_columns<N, FAST, SPLITV>(p, G, pend_i, pend_j, pend_kind, vu + 1, kGrid, dt_col, lg);
 
   if (stamp) ts3 = __builtin_amdgcn_s_memtime();
   // ---- commit: column 50 -> state, t_ += dt_ (cpp:153-158) ----
@@ -533,6 +682,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     atomicAdd(&p.stamp_out[STAMP_FILL], ts1 - ts0);
     atomicAdd(&p.stamp_out[STAMP_SCAN0], ts2 - ts1);
     atomicAdd(&p.stamp_out[STAMP_EVENTS], ts3 - ts2);
+    atomicMax(&p.stamp_out[STAMP_MAX_EVENTS], ts3 - ts2);
     atomicAdd(&p.stamp_out[STAMP_COMMIT], ts4 - ts3);
     atomicAdd(&p.stamp_out[STAMP_ARENAS], 1ull);
   }

@@ -294,6 +294,14 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.m_player = s->m_player; a.m_puck = s->m_puck;
   a.le_pp = sqrt_threshold(kRPlayer + kRPlayer, false); a.le_pk = sqrt_threshold(kRPlayer + kRPuck, false);
   a.lt_pp = sqrt_threshold(kRPlayer + kRPlayer, true);  a.lt_pk = sqrt_threshold(kRPlayer + kRPuck, true);
+  {
+    const double rp = kRPlayer, rk = kRPuck;
+    a.push101_pp = (1.01 * rp) / (rp + rp); a.push101_plk = (1.01 * rp) / (rp + rk); a.push101_pkk = (1.01 * rk) / (rp + rk);
+    a.push11_pp = (1.1 * rp) / (rp + rp);   a.push11_plk = (1.1 * rp) / (rp + rk);   a.push11_pkk = (1.1 * rk) / (rp + rk);
+    a.ratio_pp = (2 * s->m_player) / (s->m_player + s->m_player);
+    a.ratio_vs_puck = (2 * s->m_puck) / (s->m_player + s->m_puck);
+    a.ratio_vs_player = (2 * s->m_player) / (s->m_player + s->m_puck);
+  }
   a.win = (double)s->win;
   a.B = s->B;
   a.state = s->state; a.tcur = s->tcur; a.damage = s->damage;
@@ -703,14 +711,15 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   return RGS_OK;
 }
 
-// Diagnostic: per-phase shader-cycle totals of the one-lane hybrid kernel since the last reset.
-// out4: lane-pass cycles, wave-pass cycles, wave-pass rounds, total kernel cycles (summed over waves).
-int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out4) {  /* out: STAMP_N = 9 values */
+// Diagnostic: per-phase shader-cycle totals of the hybrid kernels since the last reset (or clear).
+// enable: bit 0 = stamps on for later launches, bit 1 = clear the totals first.  out: STAMP_N = 13 values.
+int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out13) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_get_stamps: null handle");
   HIP_TRY(hipSetDevice(s->device));
-  s->stamps = enable != 0;
-  if (out4) {
-    HIP_TRY(hipMemcpyAsync(out4, s->counters + CNT_N, sizeof(unsigned long long) * STAMP_N, hipMemcpyDeviceToHost, s->stream));
+  s->stamps = (enable & 1) != 0;
+  if (enable & 2) HIP_TRY(hipMemsetAsync(s->counters + CNT_N, 0, sizeof(unsigned long long) * STAMP_N, s->stream));
+  if (out13) {
+    HIP_TRY(hipMemcpyAsync(out13, s->counters + CNT_N, sizeof(unsigned long long) * STAMP_N, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   return RGS_OK;

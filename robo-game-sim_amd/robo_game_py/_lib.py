@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC, "librgs_hip.so")
+# RGS_LIB_SUFFIX selects a diagnostic / A-B build made with `make SUFFIX=...` (e.g. _stamps); unset = the product library
+LIB_PATH = os.path.join(CSRC, "librgs_hip%s.so" % os.environ.get("RGS_LIB_SUFFIX", ""))
 
 RGS_OK = 0
 RGS_ERR_ARG = -1
@@ -79,7 +80,7 @@ def build(force=False):
     args = ["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", CSRC]
     if force:
         args.append("-B")
-    subprocess.check_call(args + ["librgs_hip.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args + ["librgs_hip.so"], stdout=subprocess.DEVNULL)   # always the product library
     return LIB_PATH
 
 
