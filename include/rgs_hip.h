@@ -137,12 +137,13 @@ int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
 /* Diagnostic in-kernel stamps (s_memtime) of the hybrid kernels; only in a library built with
  * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable: bit 0 = stamps on
- * for later launches, bit 1 = clear the totals first.  out13 (may be NULL) receives 13 values since the
+ * for later launches, bit 1 = clear the totals first.  out17 (may be NULL) receives 17 values since the
  * last reset/clear.  Summed over waves: lane-pass cycles, wave-pass cycles, wave-pass rounds,
  * whole-kernel cycles; for lane group 0 of every wave pass: fill, first-scan, event-loop, commit cycles
  * and the arena count; maxima over waves: whole-kernel cycles, wave-pass cycles, rounds, and the longest
- * single event loop. */
-int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out13);
+ * single event loop; then, summed over group 0's carried-out events: cycles from the pop to the start of
+ * the carry-out, of the carry-out, of the re-scan chunks, and the event count. */
+int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out17);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
 

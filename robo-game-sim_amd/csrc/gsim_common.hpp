@@ -58,7 +58,9 @@ enum Counter : int {
   STAMP_LANE = 0, STAMP_WAVE = 1, STAMP_ROUNDS = 2, STAMP_TOTAL = 3,
   STAMP_FILL = 4, STAMP_SCAN0 = 5, STAMP_EVENTS = 6, STAMP_COMMIT = 7, STAMP_ARENAS = 8,
   // maxima over waves (atomicMax): whole kernel, wave-pass cycles, rounds; and the longest single event loop
-  STAMP_MAX_TOTAL = 9, STAMP_MAX_WAVE = 10, STAMP_MAX_ROUNDS = 11, STAMP_MAX_EVENTS = 12, STAMP_N = 13
+  STAMP_MAX_TOTAL = 9, STAMP_MAX_WAVE = 10, STAMP_MAX_ROUNDS = 11, STAMP_MAX_EVENTS = 12,
+  // inside the event loop (group 0): pop .. carry-out start, carry-out, re-scan chunks; events counted
+  STAMP_EV_HEAD = 13, STAMP_EV_CARRY = 14, STAMP_EV_SCAN = 15, STAMP_EV_COUNT = 16, STAMP_N = 17
 };
 
 // Everything one launch needs.  Arrays are SoA with the arena index fastest.

@@ -114,103 +114,106 @@ __device__ __forceinline__ void grid_sync() {
 template <int N>
 __device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuck : kRPlayer; }
 
-// One column of insertCollisions (cpp:371-498) for disc `id`: the earliest candidate among
-// UP, DOWN, RIGHT, LEFT and the other discs in entity order; strict '<' keeps the first found.
-// The pair test fl(sqrt(s)) <= R (cpp:471) is evaluated as s <= le, le = the largest double whose
-// correctly rounded square root is <= R (host-computed, StepArgs::le_*): same truth value, no sqrt.
-// partners: discs to run the pair test against (bit o).  The first scan of a step may pass the lane
-// pass' disc mask -- a pair can only overlap at a column of the untouched grid if the (superset) watch
-// fired for BOTH of its discs; every later scan passes all ones.
+// One column of insertCollisions (cpp:371-498) for disc `id` (may differ from lane to lane): the earliest
+// candidate among UP, DOWN, RIGHT, LEFT and the other discs in entity order; strict '<' keeps the
+// first found.  The pair test fl(sqrt(s)) <= R (cpp:471) is evaluated as s <= le, le = the largest
+// double whose correctly rounded square root is <= R (host-computed, StepArgs::le_*): same truth
+// value, no sqrt.
+//
+// Written for latency, since one lane group runs this inside a serial chain of up to 49 events: the
+// overlap predicates of the column (4 wall zones, E-1 distances) are evaluated first in straight-line
+// code over one batch of LDS loads; only a column with a predicate set -- rare outside sustained
+// contact -- goes on to the back-tracking arithmetic.
 template <int N, bool SPLITV>
 __device__ __forceinline__ void column_candidate(const StepArgs &p, const GridView<N, SPLITV> &G, int g, int id, double t0,
-                                                 double dt_col, unsigned partners, double &best_t, int &best_j,
-                                                 int &best_kind) {
-  using L = WaveLayout<N>;
-  const int gm = g - 1;
-  const double rad = disc_radius<N>(id);
+                                                 double dt_col, double &best_t, int &best_j, int &best_kind) {
+  constexpr int E = 2 * N + 1, PK = 2 * N;
+  const double rad = id == PK ? kRPuck : kRPlayer;
   const double kpx = G.pos(g, id, 0), kpy = G.pos(g, id, 1);
-  const double t_m = t0 + dt_col * (double)(g - 1);          // T row, cpp:201 (g-1 = 0 gives t_)
-  best_t = 1.0e9; best_j = -1; best_kind = -1;               // Collision(), Collision.h:9
-  if (kpy + rad >= kY / 2.0) {                               // cpp:374-394
-    const double mvy = G.vel(gm, id, 1);
-    if (mvy > 0) {
-      const double tc = t_m + max0(div_ieee(kY / 2.0 - rad - G.pos(gm, id, 1), mvy));
-      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = UP; }
-    }
-  }
-  if (kpy - rad <= -kY / 2.0) {                              // cpp:397-417
-    const double mvy = G.vel(gm, id, 1);
-    if (mvy < 0) {
-      const double tc = t_m + max0(div_ieee(-kY / 2.0 + rad - G.pos(gm, id, 1), mvy));
-      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = DOWN; }
-    }
-  }
-  if (kpx + rad >= kX / 2.0) {                               // cpp:420-440
-    const double mvx = G.vel(gm, id, 0);
-    if (mvx > 0) {
-      const double tc = t_m + max0(div_ieee(kX / 2.0 - rad - G.pos(gm, id, 0), mvx));
-      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = RIGHT; }
-    }
-  }
-  if (kpx - rad <= -kX / 2.0) {                              // cpp:443-463
-    const double mvx = G.vel(gm, id, 0);
-    if (mvx < 0) {
-      const double tc = t_m + max0(div_ieee(-kX / 2.0 + rad - G.pos(gm, id, 0), mvx));
-      if (tc < best_t) { best_t = tc; best_j = -1; best_kind = LEFT; }
-    }
-  }
+  unsigned near = 0u;
 #pragma unroll
-  for (int o = 0; o < L::E; ++o) {                           // cpp:466-498
-    if (o == id || !((partners >> o) & 1u)) continue;
-    const double rad_o = disc_radius<N>(o);
+  for (int o = 0; o < E; ++o) {                              // cpp:466-471, every other disc
     const double ddx = kpx - G.pos(g, o, 0), ddy = kpy - G.pos(g, o, 1);
-    const double le = (id == L::PK || o == L::PK) ? p.le_pk : p.le_pp;
-    if (ddx * ddx + ddy * ddy <= le) {                       // cpp:471
-      const double dpx = G.pos(gm, o, 0) - G.pos(gm, id, 0), dpy = G.pos(gm, o, 1) - G.pos(gm, id, 1);   // cpp:484
-      const double dvx = G.vel(gm, o, 0) - G.vel(gm, id, 0), dvy = G.vel(gm, o, 1) - G.vel(gm, id, 1);   // cpp:485
-      const double sigma = rad + rad_o;
-      const double dpdv = dpx * dvx + dpy * dvy;
-      const double dvdv = dvx * dvx + dvy * dvy;
-      const double dpdp = dpx * dpx + dpy * dpy;
-      const double d = dpdv * dpdv - dvdv * (dpdp - sigma * sigma);                            // cpp:487
-      const double dvdp = dvx * dpx + dvy * dpy;
-      if (dvdp < 0 && d >= 0) {
-        const double tc = t_m + max0(div_ieee(-(dvdp + sqrt_ieee(d)), dvdv));                 // cpp:490
-        if (tc < best_t) { best_t = tc; best_j = o; best_kind = PAIR; }
-      }
+    const double le = (o == PK || id == PK) ? p.le_pk : p.le_pp;
+    near |= (ddx * ddx + ddy * ddy <= le) ? (1u << o) : 0u;
+  }
+  near &= ~(1u << id);
+  const bool up = kpy + rad >= kY / 2.0, down = kpy - rad <= -kY / 2.0;      // cpp:374, 397
+  const bool right = kpx + rad >= kX / 2.0, left = kpx - rad <= -kX / 2.0;   // cpp:420, 443
+  best_t = 1.0e9; best_j = -1; best_kind = -1;               // Collision(), Collision.h:9
+  if (!(near != 0u || up || down || right || left)) return;
+
+  const int gm = g - 1;
+  const double mpx = G.pos(gm, id, 0), mpy = G.pos(gm, id, 1), mvx = G.vel(gm, id, 0), mvy = G.vel(gm, id, 1);
+  const double t_m = t0 + dt_col * (double)(g - 1);          // T row, cpp:201 (g-1 = 0 gives t_)
+  if (up || down || right || left) {
+    if (up && mvy > 0) {                                     // cpp:385-392
+      const double tc = t_m + max0(div_ieee(kY / 2.0 - rad - mpy, mvy));
+      if (tc < best_t) { best_t = tc; best_kind = UP; }
+    }
+    if (down && mvy < 0) {                                   // cpp:408-415
+      const double tc = t_m + max0(div_ieee(-kY / 2.0 + rad - mpy, mvy));
+      if (tc < best_t) { best_t = tc; best_kind = DOWN; }
+    }
+    if (right && mvx > 0) {                                  // cpp:431-438
+      const double tc = t_m + max0(div_ieee(kX / 2.0 - rad - mpx, mvx));
+      if (tc < best_t) { best_t = tc; best_kind = RIGHT; }
+    }
+    if (left && mvx < 0) {                                   // cpp:454-461
+      const double tc = t_m + max0(div_ieee(-kX / 2.0 + rad - mpx, mvx));
+      if (tc < best_t) { best_t = tc; best_kind = LEFT; }
+    }
+  }
+  while (near != 0u) {                                       // cpp:482-497, ascending o = entity order
+    const int o = __builtin_ctz(near);
+    near &= near - 1u;
+    const double sigma = rad + (o == PK ? kRPuck : kRPlayer);
+    const double dpx = G.pos(gm, o, 0) - mpx, dpy = G.pos(gm, o, 1) - mpy;       // cpp:484
+    const double dvx = G.vel(gm, o, 0) - mvx, dvy = G.vel(gm, o, 1) - mvy;       // cpp:485
+    const double dpdv = dpx * dvx + dpy * dvy;
+    const double dvdv = dvx * dvx + dvy * dvy;
+    const double dpdp = dpx * dpx + dpy * dpy;
+    const double d = dpdv * dpdv - dvdv * (dpdp - sigma * sigma);                // cpp:487
+    const double dvdp = dvx * dpx + dvy * dpy;
+    if ((dvdp < 0) & (d >= 0)) {                             // discs in resting contact fail this at every column
+      const double tc = t_m + max0(div_ieee(-(dvdp + sqrt_ieee(d)), dvdv));      // cpp:490
+      const bool ok = tc < best_t;
+      best_t = ok ? tc : best_t;
+      best_j = ok ? o : best_j;
+      best_kind = ok ? (int)PAIR : best_kind;
     }
   }
 }
 
-// insertCollisions' inner loop for one disc (cpp:365-506): first column >= base whose best
-// candidate satisfies t_col - t_ < dt_.  Group-uniform result.
-template <int N, int GW, bool SPLITV>
-__device__ __forceinline__ bool scan_disc(const StepArgs &p, const GridView<N, SPLITV> &G, int id, int base, double t0, double dt,
-                                          double dt_col, int lg, int gbase, unsigned partners, double &out_t,
-                                          int &out_j, int &out_kind) {
-  for (int g0 = base; g0 <= kGrid; g0 += GW) {
-    const int g = g0 + lg;
-    bool hit = false;
-    double bt = 1.0e9;
-    int bj = -1, bk = -1;
-    if (g <= kGrid) {
-      column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, partners, bt, bj, bk);
-      hit = (bt - t0 < dt);                                  // cpp:501
-    }
-    const unsigned long long m = group_ballot<GW>(hit, gbase);
-    if (m != 0ull) {
-      const int src = gbase + __builtin_ctzll(m);
-      out_t = __shfl(bt, src);
-      out_j = __shfl(bj, src);
-      out_kind = __shfl(bk, src);
-      return true;
+// The overlap predicates of grid column g for ALL discs at once (cpp:374,397,420,443,471): bit e of the
+// result = disc e is inside a wall zone or within reach of another disc at this column, i.e. exactly
+// the (disc, column) pairs for which column_candidate can produce anything.  `consider`: discs that
+// can have a flag at all (the lane pass' conservative watch; all ones when unknown) -- a pair can only
+// overlap if the watch fired for both of its discs.
+template <int N, bool SPLITV>
+__device__ __forceinline__ unsigned column_flags(const StepArgs &p, const GridView<N, SPLITV> &G, int g, unsigned consider) {
+  constexpr int E = 2 * N + 1, PK = 2 * N;
+  unsigned fl = 0u;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (N >= 4 && !((consider >> e) & 1u)) continue;         // large teams: skip the loads of unflagged discs
+    const double rad = disc_radius<N>(e);
+    const double px = G.pos(g, e, 0), py = G.pos(g, e, 1);
+    const bool wall = (py + rad >= kY / 2.0) | (py - rad <= -kY / 2.0) | (px + rad >= kX / 2.0) | (px - rad <= -kX / 2.0);
+    fl |= wall ? (1u << e) : 0u;
+#pragma unroll
+    for (int o = e + 1; o < E; ++o) {
+      const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
+      const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
+      fl |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
     }
   }
-  return false;
+  return fl & consider;
 }
 
 // Live events, one slot per disc (slot index = the event's i_).  meta < 0: empty;
-// else (seq << 8) | (kind << 5) | (j + 1).
+// else (seq << 8) | (kind << 5) | (j + 1).  Select-based (no branches): the list is replicated across
+// the lanes of a group and sits on the serial path of every event.
 template <int E>
 struct EventSlots {
   double t[E];
@@ -219,11 +222,14 @@ struct EventSlots {
 #pragma unroll
     for (int e = 0; e < E; ++e) { t[e] = 1.0e9; meta[e] = -1; }
   }
-  __device__ __forceinline__ void put(int id, double tt, int j, int kind, int seq) {
+  __device__ __forceinline__ void put(int id, double tt, int j, int kind, int seq, bool really = true) {
     const int m = (seq << 8) | (kind << 5) | (j + 1);
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (e == id) { t[e] = tt; meta[e] = m; }
+    for (int e = 0; e < E; ++e) {
+      const bool w = really & (e == id);
+      t[e] = w ? tt : t[e];
+      meta[e] = w ? m : meta[e];
+    }
   }
   __device__ __forceinline__ bool any() const {
     int acc = -1;
@@ -237,23 +243,31 @@ struct EventSlots {
     int cm = -1;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const bool valid = meta[e] >= 0;
-      const bool better = valid && (ci < 0 || t[e] < ct || (t[e] == ct && meta[e] > cm));
-      if (better) { ci = e; ct = t[e]; cm = meta[e]; }
+      const bool better = (meta[e] >= 0) & ((cm < 0) | (t[e] < ct) | ((t[e] == ct) & (meta[e] > cm)));
+      ci = better ? e : ci;
+      ct = better ? t[e] : ct;
+      cm = better ? meta[e] : cm;
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (e == ci) meta[e] = -1;
+    for (int e = 0; e < E; ++e) meta[e] = (e == ci) ? -1 : meta[e];
     cj = (cm & 31) - 1;
     ckind = (cm >> 5) & 7;
+  }
+  __device__ __forceinline__ void get(int id, double &tt, int &m) const {
+    tt = 1.0e9; m = -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      tt = (e == id) ? t[e] : tt;
+      m = (e == id) ? meta[e] : m;
+    }
   }
   // cpp:347-352: drop everything that touches ci or cj (cj = -1 for walls never matches).
   __device__ __forceinline__ void purge(int ci, int cj) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = (meta[e] & 31) - 1;
-      const bool hit = (e == ci) || (e == cj) || (j != -1 && (j == ci || j == cj));
-      if (meta[e] >= 0 && hit) meta[e] = -1;
+      const bool hit = (e == ci) | (e == cj) | ((j != -1) & ((j == ci) | (j == cj)));
+      meta[e] = hit ? -1 : meta[e];
     }
   }
 };
@@ -298,7 +312,8 @@ __device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const Grid
 }
 
 // correctOverlap of one re-integrated column (pair: cpp:581-592, wall: cpp:594-623), then the store
-// into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).
+// into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).  Select-based: the
+// square root is taken whether or not the discs overlap.
 template <int N, bool SPLITV>
 __device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
                                                  bool wall_fix) {
@@ -307,17 +322,15 @@ __device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const Gr
     const double pij = c.first ? po - x.p : x.p - po;
     const double sq = pij * pij;
     const double s = sq + quad_xor1(sq);
-    if (s <= c.lt) {
-      const double overlap = c.rsum - sqrt_ieee(s);
-      const double cc = c.push11 * overlap;
-      x.p = c.first ? x.p - cc * pij : x.p + cc * pij;
-    }
+    const double overlap = c.rsum - sqrt_ieee(s);
+    const double cc = (c.first ? -c.push11 : c.push11) * overlap;    // -(a*b) == (-a)*b exactly
+    const double moved = x.p + cc * pij;                             // x - c*pij == x + (-(c*pij))
+    x.p = (s <= c.lt) ? moved : x.p;
   } else if (c.my_axis && wall_fix) {
     const double overlap = c.positive_wall ? (x.p + c.r_own - c.wall) : (-x.p + c.r_own - c.wall);
-    if (overlap > 0) {
-      const double cc = 1.1 * overlap;
-      x.p = c.positive_wall ? x.p - cc : x.p + cc;
-    }
+    const double cc = 1.1 * overlap;
+    const double moved = c.positive_wall ? x.p - cc : x.p + cc;
+    x.p = (overlap > 0) ? moved : x.p;
   }
   if (c.store) {
     G.pos(g, c.d, c.ax) = x.p;
@@ -366,7 +379,7 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
     double bt = 1.0e9;
     int bj = -1, bk = -1;
     if (g <= hi && want) {
-      column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, ~0u, bt, bj, bk);
+      column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, bt, bj, bk);
       hit = (bt - t0 < dt);                                  // cpp:501
     }
     const unsigned long long m = group_ballot<GW>(hit, gbase);
@@ -451,40 +464,45 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   int seq = 0, base = 1, counter = 0;
   bool scored = false;
   unsigned n_resolved = 0, n_skipped = 0, n_overflow = 0;
-  if ((discmask & 0xFFFFu) == 0xFFFFu) {
-    // No lane pass ran before this (wave-per-arena kernel): derive the per-disc flags from the grid
-    // itself -- lane <-> column, the reference's own overlap predicates (cpp:374,397,420,443,471) for
-    // every disc and pair of the column, OR-ed over the columns.  A disc without a flag has no
-    // candidate at any column, so its first scan is skipped (one pre-pass instead of E scans).
-    unsigned mine = 0u;
-    for (int g = 1 + lg; g <= kGrid; g += GW) {
+  // First pass, checks = all discs (cpp:145 -> insertCollisions): lane <-> grid column.  Each chunk of
+  // GW columns first gets the overlap predicates of every disc in one straight-line pass
+  // (column_flags); only (disc, column) pairs with a predicate set can yield a candidate, so only those
+  // are evaluated, disc by disc.  The scans of different discs do not influence each other (nothing
+  // writes the grid), so walking the columns chunk-wise for all discs together finds, for every disc,
+  // the same first admissible column as the reference's disc-by-disc order; the list order the
+  // reference gets from that order (ascending disc id) is restored by numbering these events with
+  // their disc id (seq = id; later insertions count on from E).
+  {
+    const unsigned consider = (discmask & 0xFFFFu) == 0xFFFFu ? ((1u << E) - 1u) : (discmask & 0xFFFFu);
+    int scan_from = (int)((discmask >> 16) & 63u);           // first column that can hold a candidate (1 when unknown)
+    scan_from = scan_from < 1 ? 1 : (scan_from > kGrid ? kGrid : scan_from);
+    unsigned open = consider;                                // discs still looking for their first event
+    for (int g0 = scan_from; g0 <= kGrid && open != 0u; g0 += GW) {
+      const int g = g0 + lg;
+      const unsigned fl = g <= kGrid ? (column_flags<N, SPLITV>(p, G, g, consider) & open) : 0u;
+      if (group_ballot<GW>(fl != 0u, gbase) == 0ull) continue;
+      unsigned todo = 0u;                                    // union of the lanes' flags (group-uniform)
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const double rad = disc_radius<N>(e);
-        const double px = G.pos(g, e, 0), py = G.pos(g, e, 1);
-        const bool wall = (py + rad >= kY / 2.0) || (py - rad <= -kY / 2.0) || (px + rad >= kX / 2.0) ||
-                          (px - rad <= -kX / 2.0);
-        mine |= wall ? (1u << e) : 0u;
-#pragma unroll
-        for (int o = e + 1; o < E; ++o) {
-          const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
-          const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
-          mine |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
+      for (int e = 0; e < E; ++e) todo |= group_ballot<GW>(((fl >> e) & 1u) != 0u, gbase) != 0ull ? (1u << e) : 0u;
+      while (todo != 0u) {
+        const int id = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        bool hit = false;
+        double bt = 1.0e9;
+        int bj = -1, bk = -1;
+        if ((fl >> id) & 1u) {
+          column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, bt, bj, bk);
+          hit = (bt - t0 < dt);                              // cpp:501
+        }
+        const unsigned long long m = group_ballot<GW>(hit, gbase);
+        if (m != 0ull) {
+          const int src = gbase + __builtin_ctzll(m);
+          ev.put(id, __shfl(bt, src), __shfl(bj, src), __shfl(bk, src), id);
+          open &= ~(1u << id);
         }
       }
     }
-    unsigned all = 0u;
-#pragma unroll
-    for (int e = 0; e < E; ++e) all |= group_ballot<GW>(((mine >> e) & 1u) != 0u, gbase) != 0ull ? (1u << e) : 0u;
-    discmask = all | (1u << 16);
-  }
-  int scan_from = (int)((discmask >> 16) & 63u);
-  scan_from = scan_from < 1 ? 1 : (scan_from > kGrid ? kGrid : scan_from);
-#pragma unroll
-  for (int id = 0; id < E; ++id) {                           // first pass: checks = all discs, cpp:145
-    double tt; int jj, kk;
-    if (((discmask >> id) & 1u) && scan_disc<N, GW, SPLITV>(p, G, id, scan_from, t0, dt, dt_col, lg, gbase, discmask & 0xFFFFu, tt, jj, kk))
-      ev.put(id, tt, jj, kk, seq++);
+    seq = E;
   }
   counter = 1;
   const bool had_events = ev.any();
@@ -511,14 +529,54 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   // reads.  With noise the draws are bound to the RK4 call order and the whole remainder is produced
   // at once (one chunk).
   int pend_i = -1, pend_j = -1, pend_kind = -1, vu = kGrid;   // group-uniform
+  int last_i = -1, last_j = -1, last_kind = -1;              // the event carried out last (fixed-point shortcut below)
+  double last_t = 0.0, last_damage = 0.0;
+  bool last_overflow = false;
 
   while (ev.any() && counter < kLoopCap) {
     int ci, cj, ckind;
     double ct;
+    unsigned long long te0 = 0, te1 = 0, te2 = 0;
+    if (stamp) te0 = __builtin_amdgcn_s_memtime();
     ev.pop(ci, ct, cj, ckind);                               // cpp:227
     counter++;
     if ((ci == PK || cj == PK) && scored) { n_skipped++; continue; }   // cpp:230-231
     const bool is_pair = ckind == PAIR;
+    bool repeats = !NOISE && last_i >= 0 && ct == last_t && ckind == last_kind &&
+                   ((ci == last_i && cj == last_j) || (ci == last_j && cj == last_i));
+    if (repeats && is_pair) {                                // the partner's own event, if it has one (slot cj)
+      double tb; int mb;
+      ev.get(cj, tb, mb);
+      repeats = mb < 0 || tb > ct || ((mb & 31) - 1 == ci && ((mb >> 5) & 7) == PAIR);
+    }
+    if (repeats) {
+      // Fixed point.  This event has the time, discs and kind of the one carried out just before it, so
+      // it starts from the same column base-1 (that carry-out only wrote columns >= base) and rebuilds,
+      // value for value, the columns that are already there; its re-scans then find what the last
+      // re-scans found on that same grid, i.e. they re-insert this event (slot i) and the partner's
+      // event b (slot j) with unchanged values, this one first.  The next pop therefore returns this
+      // event again -- directly if b is later, and with i and j swapped if b is its equal-time mirror
+      // image (b then wins the tie as the newer entry; cpp:259-274 are symmetric in i and j, so the
+      // orientation changes no value) -- and so on: the reference repeats the identical iteration until
+      // the cap ends the step (cpp:150).  That is what a puck spawned inside a player or a disc
+      // pressed into a wall does.  (An equal-time b that is something else -- a wall event, another
+      // partner -- would be popped next instead; then this is not a fixed point and the event is
+      // carried out normally.)  Nothing but the counters and, for two players, the damage sums changes
+      // during those iterations, so they are booked here without being recomputed.
+      const int reps = kLoopCap - counter + 1;               // this iteration and all that follow, up to the cap
+      n_resolved += (unsigned)reps;
+      n_overflow += last_overflow ? (unsigned)reps : 0u;
+      if (is_pair && ci != PK && cj != PK && lg == 0) {       // cpp:277-282, one rounding per iteration like the reference
+        constexpr int Pn = L::P;
+        double dij = p.damage[(long long)(ci * Pn + cj) * B + a], dji = p.damage[(long long)(cj * Pn + ci) * B + a];
+        for (int r = 0; r < reps; ++r) { dij += last_damage; dji += last_damage; }
+        p.damage[(long long)(ci * Pn + cj) * B + a] = dij;
+        p.damage[(long long)(cj * Pn + ci) * B + a] = dji;
+      }
+      counter = kLoopCap;
+      ev.put(ci, ct, cj, ckind, seq++);                      // the list is not empty when the cap ends the loop
+      break;
+    }
     if (!NOISE && pend_i >= 0) {
       const bool same = is_pair ? (pend_kind == PAIR && ((ci == pend_i && cj == pend_j) || (ci == pend_j && cj == pend_i)))
                                 : (pend_kind != PAIR && ci == pend_i);
@@ -528,6 +586,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       }
     }
     base = (int)__builtin_floor(div_ieee(ct - t0, dt_col)) + 1;        // cpp:237
+    last_i = ci; last_j = cj; last_kind = ckind; last_t = ct; last_overflow = base > kGrid; last_damage = 0.0;
     if (base > kGrid) { base = kGrid; n_overflow++; }        // reference: out-of-bounds column
     if (base < 1) base = 1;
     n_resolved++;
@@ -539,6 +598,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
 
     // Lanes 0,1 carry disc i (x, y); lanes 2,3 carry disc j for a pair event and a harmless
     // duplicate of disc i for a wall event, so both kinds share one instruction stream.
+    if (stamp) te1 = __builtin_amdgcn_s_memtime();
     const EventLane<N> el = event_lane<N, SPLITV>(p, G, ci, cj, ckind, lg);
     Chain x{0.0, 0.0};
     bool fast = false, goal = false;
@@ -565,11 +625,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           const double pij = el.first ? po - x.p : x.p - po;
           const double sq = pij * pij;
           const double s = sq + quad_xor1(sq);
-          if (s <= el.lt) {
-            const double overlap = el.rsum - sqrt_ieee(s);
-            const double c = el.push101 * overlap;           // ((1.01*r)/(ri+rj))*overlap
-            x.p = el.first ? x.p - c * pij : x.p + c * pij;
-          }
+          const double overlap = el.rsum - sqrt_ieee(s);
+          const double c = (el.first ? -el.push101 : el.push101) * overlap;   // ((1.01*r)/(ri+rj))*overlap, sign of the push
+          const double moved = x.p + c * pij;                // x - c*pij == x + (-c)*pij exactly
+          x.p = (s <= el.lt) ? moved : x.p;                  // only if overlap > 0
         }
         {                                                    // elastic impulse, cpp:268-274
           const double po = quad_xor2(x.p), vo = quad_xor2(x.v);
@@ -581,18 +640,18 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           if (ci != PK && cj != PK) {                        // damage, cpp:277-282
             const double dvsq = dv * dv;
             const double dv_sq = 0.01 * (dvsq + quad_xor1(dvsq));
+            last_damage = p.m_player * dv_sq;                // lane 0 of the group keeps it for the fixed-point shortcut
             if (lg == 0) {
               constexpr int Pn = L::P;
-              p.damage[(long long)(ci * Pn + cj) * B + a] += p.m_player * dv_sq;
-              p.damage[(long long)(cj * Pn + ci) * B + a] += p.m_player * dv_sq;
+              p.damage[(long long)(ci * Pn + cj) * B + a] += last_damage;
+              p.damage[(long long)(cj * Pn + ci) * B + a] += last_damage;
             }
           }
           x.v = x.v - s * dp;
         }
       } else {                                               // wall, cpp:300-327
-        if (el.my_axis) {                                    // cpp:314-317
-          if (el.positive_wall ? (x.v > 0) : (x.v < 0)) x.v *= -1.0;
-        }
+        const bool flip = el.my_axis & (el.positive_wall ? (x.v > 0) : (x.v < 0));   // cpp:314-317
+        x.v = flip ? -x.v : x.v;                             // v * -1.0
         const double py = quad_lane1(x.p);
         goal = el.d == PK && (ckind == LEFT || ckind == RIGHT) && py < kGoalH / 2.0 && py > -kGoalH / 2.0;  // cpp:321-322
       }
@@ -613,6 +672,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     }
     grid_sync<SPLITV>();
 
+    if (stamp) te2 = __builtin_amdgcn_s_memtime();
     ev.purge(ci, cj);                                        // cpp:347-352
     // re-scan i_ then j_ (cpp:355-357 -> 147) over the columns as they are produced
     bool done_i = false, done_j = cj < 0, found_i = false, found_j = false;
@@ -650,8 +710,16 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     }
     vu = hi;
     if (vu < kGrid) { pend_i = ci; pend_j = cj; pend_kind = ckind; } else pend_i = -1;
-    if (found_i) ev.put(ci, ti, ji, ki, seq++);
-    if (found_j) ev.put(cj, tj, jj, kj, seq++);
+    ev.put(ci, ti, ji, ki, seq, found_i);
+    seq += found_i ? 1 : 0;
+    ev.put(cj, tj, jj, kj, seq, found_j);
+    seq += found_j ? 1 : 0;
+    if (stamp && lg == 0) {
+      atomicAdd(&p.stamp_out[STAMP_EV_HEAD], te1 - te0);
+      atomicAdd(&p.stamp_out[STAMP_EV_CARRY], te2 - te1);
+      atomicAdd(&p.stamp_out[STAMP_EV_SCAN], __builtin_amdgcn_s_memtime() - te2);
+      atomicAdd(&p.stamp_out[STAMP_EV_COUNT], 1ull);
+    }
   }
   if (!NOISE && pend_i >= 0)                                 // whatever is still pending is part of the final grid
     finish_columns<N, FAST, SPLITV>(p, G, pend_i, pend_j, pend_kind, vu + 1, kGrid, dt_col, lg);

@@ -712,14 +712,14 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
 }
 
 // Diagnostic: per-phase shader-cycle totals of the hybrid kernels since the last reset (or clear).
-// enable: bit 0 = stamps on for later launches, bit 1 = clear the totals first.  out: STAMP_N = 13 values.
-int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out13) {
+// enable: bit 0 = stamps on for later launches, bit 1 = clear the totals first.  out: STAMP_N = 17 values.
+int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out17) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_get_stamps: null handle");
   HIP_TRY(hipSetDevice(s->device));
   s->stamps = (enable & 1) != 0;
   if (enable & 2) HIP_TRY(hipMemsetAsync(s->counters + CNT_N, 0, sizeof(unsigned long long) * STAMP_N, s->stream));
-  if (out13) {
-    HIP_TRY(hipMemcpyAsync(out13, s->counters + CNT_N, sizeof(unsigned long long) * STAMP_N, hipMemcpyDeviceToHost, s->stream));
+  if (out17) {
+    HIP_TRY(hipMemcpyAsync(out17, s->counters + CNT_N, sizeof(unsigned long long) * STAMP_N, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   return RGS_OK;
