@@ -63,3 +63,44 @@ def chase_controls(state, n_per_team, speed=4.0):
         nrm = np.where(nrm > 0, nrm, 1.0)
         u[e] = speed * d / nrm
     return u
+
+
+def mc_inputs(seeds, n_per_team=2):
+    """Per-run control generator of the Monte-Carlo configuration (BASELINE C4).
+
+    py/MonteCarlo.py:23,29 hands run i the seed i; with noise = 0 that seed has no effect on the
+    physics, so here it seeds the run's open-loop control generator instead: the run's per-player
+    amplitude A ~ U(0.5, 4) and phase phi ~ U(0, 2 pi) come from np.random.default_rng(seed).
+    Returns (amp, phase), each of shape (P, len(seeds)).
+    """
+    P = 2 * n_per_team
+    seeds = np.asarray(seeds, dtype=np.int64)
+    amp = np.empty((P, len(seeds)))
+    phase = np.empty((P, len(seeds)))
+    for k, s in enumerate(seeds):
+        rng = np.random.default_rng(int(s))
+        amp[:, k] = rng.uniform(0.5, 4.0, P)
+        phase[:, k] = rng.uniform(0.0, 2.0 * math.pi, P)
+    return amp, phase
+
+
+def device_circle_table(torch, device, amp, phase, times, zero_first=False, chunk=64):
+    """circle_controls evaluated on the GPU: (K, P, 2, B) float64 tensor resident in HBM.
+
+    Device cos/sin differ from numpy's in the last ulp, so whoever re-computes a run driven by this
+    table on the CPU must use the table's own values (bench.py downloads the sampled arenas'
+    columns).  zero_first: step 0 commands nothing (py/MonteCarlo.py:33).
+    """
+    K = len(times)
+    P, B = amp.shape
+    table = torch.empty((K, P, 2, B), dtype=torch.float64, device=device)
+    amp_d = torch.from_numpy(np.ascontiguousarray(amp)).to(device)
+    ph_d = torch.from_numpy(np.ascontiguousarray(phase)).to(device)
+    t_d = torch.from_numpy(np.ascontiguousarray(times)).to(device)
+    for k0 in range(0, K, chunk):
+        arg = t_d[k0:k0 + chunk, None, None] + ph_d[None]
+        table[k0:k0 + chunk, :, 0, :] = amp_d[None] * torch.cos(arg)
+        table[k0:k0 + chunk, :, 1, :] = amp_d[None] * torch.sin(arg)
+    if zero_first and K > 0:
+        table[0] = 0.0
+    return table

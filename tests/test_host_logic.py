@@ -1,5 +1,7 @@
 """Host-side mirror of the reference interface: argument handling, log record, layouts."""
+import os
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -74,3 +76,51 @@ def test_partition_covers_everything_once(rgp):
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w_ - 1))
         sizes = [hi - lo for lo, hi in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_starts_one_rank_per_gpu_when_not_under_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE) must start N ranks itself, before touching the GPU."""
+    import importlib
+    import subprocess
+    sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if sys_path_root not in sys.path:
+        sys.path.insert(0, sys_path_root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the children's return code is passed on
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+
+def test_bench_presets_match_baseline_configs():
+    import importlib
+    bench = importlib.import_module("bench")
+    a = bench.parse_args(["--config", "c4"])
+    assert (a.n_per_team, a.arenas, a.dt, a.win, a.steps, a.warmup) == (2, 131072, 0.05, 4, 201, 0)
+    a = bench.parse_args([])
+    assert (a.n_per_team, a.arenas, a.dt, a.steps, a.warmup) == (2, 65536, 0.01, 1000, 10)
+    a = bench.parse_args(["--config", "c5", "--steps", "20", "--warmup", "5"])
+    assert (a.n_per_team, a.arenas, a.dt, a.steps, a.warmup) == (4, 32768, 0.05, 20, 5)
+    assert bench.algorithmic_bytes_per_arena_step(2) == 416 and bench.algorithmic_bytes_per_arena_step(7) == 1216
+
+
+def test_mc_inputs_are_a_function_of_the_run_seed_only():
+    from robo_game_py import workloads as w
+    a1, p1 = w.mc_inputs(np.arange(1, 9), 2)
+    a2, p2 = w.mc_inputs(np.arange(5, 9), 2)
+    assert np.array_equal(a1[:, 4:], a2) and np.array_equal(p1[:, 4:], p2)      # sharding the runs changes nothing
+    assert a1.shape == (4, 8) and np.all((a1 >= 0.5) & (a1 < 4.0)) and np.all((p1 >= 0) & (p1 < 2 * np.pi))
