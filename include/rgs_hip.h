@@ -42,7 +42,9 @@ enum {
   RGS_VARIANT_AUTO = 0,
   RGS_VARIANT_WAVE = 1,      /* one wavefront owns one arena, grid in LDS */
   RGS_VARIANT_HYBRID = 2,    /* lane-per-arena streaming pass + LDS event pass */
-  RGS_VARIANT_HYBRID2 = 3    /* the same with two lanes (x chains, y chains) per arena */
+  RGS_VARIANT_HYBRID2 = 3,   /* the same with two lanes (x chains, y chains) per arena */
+  RGS_VARIANT_POOL = 4       /* HYBRID whose flagged arena-steps go through one chip-wide queue: full event-pass rounds,
+                                wavefronts help each other and the early finishers serve the queue until the launch ends */
 };
 
 /* Human-readable text for the most recent failure on this thread. */
@@ -144,6 +146,11 @@ int rgs_get_counters(rgs_sim *sim, int64_t *out8);
  * single event loop; then, summed over group 0's carried-out events: cycles from the pop to the start of
  * the carry-out, of the carry-out, of the re-scan chunks, and the event count. */
 int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out17);
+
+/* Debug aid (GPU AddressSanitizer is not available here): with RGS_DEBUG_GUARD_BYTES=<n> in the environment every
+ * device buffer of a handle carries n guard bytes on both sides; this call returns RGS_ERR_HIP and names the first
+ * buffer whose guard zone was overwritten.  Without the variable it is a no-op returning RGS_OK. */
+int rgs_debug_check_guards(rgs_sim *sim);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
 

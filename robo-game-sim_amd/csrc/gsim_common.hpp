@@ -53,6 +53,7 @@ enum Counter : int {
   CNT_SKIPPED = 3,        // puck events dropped after a goal, cpp:230-231
   CNT_EVENT_STEPS = 4,    // arena-steps whose first scan found an event
   CNT_FLAGGED = 5,        // hybrid: arena-steps the lane pass handed to the wave pass
+  CNT_POOL_TIMEOUT = 6,   // pooled kernel: a bounded wait ran out (protocol error; results invalid)
   CNT_N = 8,
   // diagnostic stamps (StepArgs::stamps != 0): summed over waves, shader cycles
   STAMP_LANE = 0, STAMP_WAVE = 1, STAMP_ROUNDS = 2, STAMP_TOTAL = 3,
@@ -104,7 +105,38 @@ struct StepArgs {
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]
+  // pooled kernel (k_step_pool): the chip-wide queue of flagged arena-steps.  q_ctrl[0] = tickets issued
+  // (tail), [1] = tickets claimed (head), [2] = wavefronts that have finished their steps (monotonic over
+  // launches: this launch is over at q_done_target); q_task[t & q_mask] = payload of ticket t, valid once
+  // q_seq[t & q_mask] == (unsigned)(t + 1); q_pending[w] = tasks of home wavefront w not yet completed.
+  unsigned long long *q_ctrl;
+  unsigned long long *q_task;
+  unsigned *q_seq;
+  int *q_pending;
+  unsigned long long q_mask;
+  unsigned long long q_done_target;
+  int q_stay;                        // 1: the grid fits the chip at once, finished wavefronts keep serving the queue
 };
+
+// Global-memory accessors of the per-arena arrays (state, tcur, damage).  COH = false: plain loads and
+// stores -- an arena is only ever touched by the one wavefront that owns it for the whole launch.
+// COH = true (pooled kernel, gsim_kernels.hpp): arenas migrate between wavefronts on other CUs and
+// XCDs inside a launch, so every access is an agent-scope relaxed atomic, which the compiler emits as
+// an `sc1` (write-through / L1- and cross-XCD-L2-coherent) global access; the hand-over itself is
+// ordered by a vmcnt(0) drain and a flag or counter (MI355X_MICROARCH.md, "Valid forms", row 1 / 3).
+template <bool COH>
+__device__ __forceinline__ double gld(const double *q) {
+  if (COH)
+    return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *q;
+}
+template <bool COH>
+__device__ __forceinline__ void gst(double *q, double v) {
+  if (COH)
+    __hip_atomic_store((unsigned long long *)q, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *q = v;
+}
 
 // State-vector row of disc e's first component (include/SimState.h:14-23; players after the puck).
 template <int N>
@@ -220,12 +252,12 @@ __device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, 
 
 // Snapshot of arena a's state rows into the trajectory buffer (see StepArgs::traj).  Called by the
 // `nl` lanes that own the arena after its step k0 (0-based) is complete and visible.
-template <int N>
+template <int N, bool COH = false>
 __device__ __forceinline__ void snapshot_state(const StepArgs &p, long long a, int k0, int lane, int nl) {
   if (p.traj == nullptr || (k0 + 1) % p.traj_every != 0) return;
   constexpr int S = 2 + 4 * (2 * N + 1);
   double *dst = p.traj + (long long)((k0 + 1) / p.traj_every - 1) * S * p.B;
-  for (int r = lane; r < S; r += nl) dst[(long long)r * p.B + a] = p.state[(long long)r * p.B + a];
+  for (int r = lane; r < S; r += nl) dst[(long long)r * p.B + a] = gld<COH>(&p.state[(long long)r * p.B + a]);
 }
 
 // Orders LDS traffic between lanes of ONE wavefront: LDS operations of a wave

@@ -150,22 +150,22 @@ __device__ __forceinline__ void rk4_all_chains(double *p, double *v, const doubl
 // Chains are numbered c = 2*e + axis: the puck's two chains come last (c >= 2*P).
 // Returns true when the arena must take the wave pass; discmask then holds the discs whose watch
 // fired (all discs when the division guard tripped).
-template <int N, int MODE>
+template <int N, int MODE, bool COH = false>
 __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__restrict__ ctl, long long a,
                                           unsigned &discmask) {
   constexpr int P = 2 * N, E = P + 1, PK = P, M = 2 * E;
   const long long B = p.B;
-  const double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
+  const double TAS = gld<COH>(&p.state[0 * B + a]), TBS = gld<COH>(&p.state[1 * B + a]);
   if (!(TAS < p.win && TBS < p.win)) return false;          // decided: run() is a no-op, cpp:121-123
 
   double pos[M], vel[M], u[M];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int row = state_row<N>(e);
-    pos[2 * e + 0] = p.state[(long long)(row + 0) * B + a];
-    pos[2 * e + 1] = p.state[(long long)(row + 1) * B + a];
-    vel[2 * e + 0] = p.state[(long long)(row + 2) * B + a];
-    vel[2 * e + 1] = p.state[(long long)(row + 3) * B + a];
+    pos[2 * e + 0] = gld<COH>(&p.state[(long long)(row + 0) * B + a]);
+    pos[2 * e + 1] = gld<COH>(&p.state[(long long)(row + 1) * B + a]);
+    vel[2 * e + 0] = gld<COH>(&p.state[(long long)(row + 2) * B + a]);
+    vel[2 * e + 1] = gld<COH>(&p.state[(long long)(row + 3) * B + a]);
     if (e != PK) {
       u[2 * e + 0] = ctl[(long long)(2 * e + 0) * B + a];
       u[2 * e + 1] = ctl[(long long)(2 * e + 1) * B + a];
@@ -276,12 +276,12 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
 #pragma unroll
   for (int e = 0; e < E; ++e) {                             // cpp:153-157
     const int row = state_row<N>(e);
-    p.state[(long long)(row + 0) * B + a] = pos[2 * e + 0];
-    p.state[(long long)(row + 1) * B + a] = pos[2 * e + 1];
-    p.state[(long long)(row + 2) * B + a] = vel[2 * e + 0];
-    p.state[(long long)(row + 3) * B + a] = vel[2 * e + 1];
+    gst<COH>(&p.state[(long long)(row + 0) * B + a], pos[2 * e + 0]);
+    gst<COH>(&p.state[(long long)(row + 1) * B + a], pos[2 * e + 1]);
+    gst<COH>(&p.state[(long long)(row + 2) * B + a], vel[2 * e + 0]);
+    gst<COH>(&p.state[(long long)(row + 3) * B + a], vel[2 * e + 1]);
   }
-  p.tcur[a] = p.tcur[a] + p.dt;                             // cpp:158
+  gst<COH>(&p.tcur[a], gld<COH>(&p.tcur[a]) + p.dt);                             // cpp:158
   return false;
 }
 
@@ -297,20 +297,20 @@ __device__ __forceinline__ unsigned quad_xor1_u32(unsigned x) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);
 }
 
-template <int N, int MODE>
+template <int N, int MODE, bool COH = false>
 __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double *__restrict__ ctl, long long a, int ax,
                                                 unsigned &discmask) {
   constexpr int P = 2 * N, E = P + 1, PK = P;
   const long long B = p.B;
-  const double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
+  const double TAS = gld<COH>(&p.state[0 * B + a]), TBS = gld<COH>(&p.state[1 * B + a]);
   if (!(TAS < p.win && TBS < p.win)) return false;          // decided (both lanes of the arena agree)
 
   double pos[E], vel[E], u[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int row = state_row<N>(e);
-    pos[e] = p.state[(long long)(row + ax) * B + a];
-    vel[e] = p.state[(long long)(row + 2 + ax) * B + a];
+    pos[e] = gld<COH>(&p.state[(long long)(row + ax) * B + a]);
+    vel[e] = gld<COH>(&p.state[(long long)(row + 2 + ax) * B + a]);
     u[e] = e != PK ? ctl[(long long)(2 * e + ax) * B + a] : 0.0;   // cpp:188
   }
   const double dt_col = p.dt_col;
@@ -397,10 +397,10 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
 #pragma unroll
   for (int e = 0; e < E; ++e) {                             // cpp:153-157, this lane's axis
     const int row = state_row<N>(e);
-    p.state[(long long)(row + ax) * B + a] = pos[e];
-    p.state[(long long)(row + 2 + ax) * B + a] = vel[e];
+    gst<COH>(&p.state[(long long)(row + ax) * B + a], pos[e]);
+    gst<COH>(&p.state[(long long)(row + 2 + ax) * B + a], vel[e]);
   }
-  if (ax == 0) p.tcur[a] = p.tcur[a] + p.dt;                // cpp:158
+  if (ax == 0) gst<COH>(&p.tcur[a], gld<COH>(&p.tcur[a]) + p.dt);                // cpp:158
   return false;
 }
 

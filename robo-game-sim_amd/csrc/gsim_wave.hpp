@@ -75,6 +75,18 @@ struct WaveLayout {
   static constexpr int DOUBLES = U_OFF + 2 * E + 1; // per arena (odd => groups shift banks)
 };
 
+#ifndef GSIM_DEBUG_BOUNDS
+#define GSIM_DEBUG_BOUNDS 0
+#endif
+// Debug builds (make EXTRA=-DGSIM_DEBUG_BOUNDS=1): every grid access checks its indices; violations are counted
+// in the diagnostic stamp area (rgs_get_stamps: [0] bad vel() indices, [1] the last one, [2]/[3] the same for
+// pos()) and redirected to element 0.  GPU AddressSanitizer is not available on this pool.
+#if GSIM_DEBUG_BOUNDS
+#define GSIM_GRID_DBG(p) , (p).stamp_out
+#else
+#define GSIM_GRID_DBG(p)
+#endif
+
 // The 51-column grid of one arena.  SPLITV = false: positions and velocities side by side in LDS
 // (WaveLayout).  SPLITV = true (two-lane hybrid from 6v6 up): LDS keeps the positions only -- every
 // scan reads them, for every disc, at every column -- and the velocity rows, which are read only when a
@@ -90,8 +102,27 @@ struct GridView {
   static constexpr int GV_DOUBLES = SPLITV ? kCols * 2 * E : 0;
   double *lds;
   double *gv;
-  __device__ __forceinline__ double &pos(int g, int e, int ax) const { return lds[g * CS + (SPLITV ? 2 : 4) * e + ax]; }
+#if GSIM_DEBUG_BOUNDS
+  unsigned long long *dbg;
+#endif
+  __device__ __forceinline__ double &pos(int g, int e, int ax) const {
+#if GSIM_DEBUG_BOUNDS
+    if (g < 0 || g > kGrid || e < 0 || e >= E || ax < 0 || ax > 1) {
+      atomicAdd(&dbg[2], 1ull);
+      dbg[3] = ((unsigned long long)(unsigned)g << 32) | ((unsigned long long)(unsigned)(e & 0xFFFF) << 16) | (unsigned)(ax & 0xFFFF);
+      g = 0; e = 0; ax = 0;
+    }
+#endif
+    return lds[g * CS + (SPLITV ? 2 : 4) * e + ax];
+  }
   __device__ __forceinline__ double &vel(int g, int e, int ax) const {
+#if GSIM_DEBUG_BOUNDS                                       // software bounds check of the grid indices (debug builds only)
+    if (g < 0 || g > kGrid || e < 0 || e >= E || ax < 0 || ax > 1) {
+      atomicAdd(&dbg[0], 1ull);
+      dbg[1] = ((unsigned long long)(unsigned)g << 32) | ((unsigned long long)(unsigned)(e & 0xFFFF) << 16) | (unsigned)(ax & 0xFFFF);
+      g = 0; e = 0; ax = 0;
+    }
+#endif
     if (SPLITV) return gv[g * (2 * E) + 2 * e + ax];
     return lds[g * CS + 4 * e + 2 + ax];
   }
@@ -412,16 +443,16 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // column (cpp:255-256, 287-288, 294-295 / 309, 331, 338); the puck draws nothing.  `cur` is that
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
-template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false>
+template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false, bool COH = false>
 __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
                                  const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
   constexpr int E = L::E, PK = L::PK;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
   const long long B = p.B;
-  double TAS = p.state[0 * B + a], TBS = p.state[1 * B + a];
+  double TAS = gld<COH>(&p.state[0 * B + a]), TBS = gld<COH>(&p.state[1 * B + a]);
   if (!(TAS < p.win && TBS < p.win)) return;                 // undecided(), cpp:57-60,121
-  const double t0 = p.tcur[a];
+  const double t0 = gld<COH>(&p.tcur[a]);
   const double dt = p.dt, dt_col = p.dt_col;
   const double *tape = NOISE ? p.tape + a * (long long)p.tape_len : nullptr;
   const int tape_last = NOISE ? p.tape_len - 8 : 0;         // last legal start of an 8-draw record
@@ -435,8 +466,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
     Chain x;
-    x.p = p.state[(long long)(row + ax) * B + a];
-    x.v = p.state[(long long)(row + 2 + ax) * B + a];
+    x.p = gld<COH>(&p.state[(long long)(row + ax) * B + a]);
+    x.v = gld<COH>(&p.state[(long long)(row + 2 + ax) * B + a]);
     double u = 0.0, coef = 0.2, tau = p.tau_puck, inv = p.inv_tau_puck;   // cpp:188: puck input is (0, 0)
     if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; inv = p.inv_tau_player; }
     G.ctl(e, ax) = u;
@@ -568,10 +599,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       n_overflow += last_overflow ? (unsigned)reps : 0u;
       if (is_pair && ci != PK && cj != PK && lg == 0) {       // cpp:277-282, one rounding per iteration like the reference
         constexpr int Pn = L::P;
-        double dij = p.damage[(long long)(ci * Pn + cj) * B + a], dji = p.damage[(long long)(cj * Pn + ci) * B + a];
+        double dij = gld<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a]), dji = gld<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a]);
         for (int r = 0; r < reps; ++r) { dij += last_damage; dji += last_damage; }
-        p.damage[(long long)(ci * Pn + cj) * B + a] = dij;
-        p.damage[(long long)(cj * Pn + ci) * B + a] = dji;
+        gst<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a], dij);
+        gst<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a], dji);
       }
       counter = kLoopCap;
       ev.put(ci, ct, cj, ckind, seq++);                      // the list is not empty when the cap ends the loop
@@ -643,8 +674,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
             last_damage = p.m_player * dv_sq;                // lane 0 of the group keeps it for the fixed-point shortcut
             if (lg == 0) {
               constexpr int Pn = L::P;
-              p.damage[(long long)(ci * Pn + cj) * B + a] += last_damage;
-              p.damage[(long long)(cj * Pn + ci) * B + a] += last_damage;
+              gst<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a], gld<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a]) + last_damage);
+              gst<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a], gld<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a]) + last_damage);
             }
           }
           x.v = x.v - s * dp;
@@ -729,13 +760,13 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   if (lg < 2 * E) {
     const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
-    p.state[(long long)(row + ax) * B + a] = G.pos(kGrid, e, ax);
-    p.state[(long long)(row + 2 + ax) * B + a] = G.vel(kGrid, e, ax);
+    gst<COH>(&p.state[(long long)(row + ax) * B + a], G.pos(kGrid, e, ax));
+    gst<COH>(&p.state[(long long)(row + 2 + ax) * B + a], G.vel(kGrid, e, ax));
   }
   if (lg == 0) {
     if (NOISE) p.consumed[a] = cur;
-    p.tcur[a] = t0 + dt;
-    if (scored) { p.state[0 * B + a] = TAS; p.state[1 * B + a] = TBS; }
+    gst<COH>(&p.tcur[a], t0 + dt);
+    if (scored) { gst<COH>(&p.state[0 * B + a], TAS); gst<COH>(&p.state[1 * B + a], TBS); }
     if (had_events) {
       atomicAdd(&p.counters[CNT_EVENT_STEPS], 1ull);
       if (n_resolved) atomicAdd(&p.counters[CNT_RESOLVED], (unsigned long long)n_resolved);

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <cstring>
 #include <string>
@@ -69,7 +70,10 @@ __global__ void k_selftest(const double *a, const double *b, long long n, double
 // Host side
 // ---------------------------------------------------------------------------------------
 
+struct GuardedBuffer { const char *name; char *base; size_t bytes; };
+
 struct rgs_sim {
+  std::vector<GuardedBuffer> guards;   // every device buffer of this handle (debug guard zones, see dev_alloc)
   long long B = 0;
   int n = 2, P = 4, E = 5, S = 22;
   int device = 0;
@@ -105,9 +109,52 @@ struct rgs_sim {
   double *vgrid = nullptr;         // split-grid velocity rows (two-lane hybrid, n >= 4)
   size_t vgrid_cap = 0;
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
+  // pooled kernel: chip-wide task queue (gsim_kernels.hpp, k_step_pool)
+  unsigned long long *q_ctrl = nullptr, *q_task = nullptr;
+  unsigned *q_seq = nullptr;
+  int *q_pending = nullptr;
+  unsigned long long q_slots = 0;  // ring size, a power of two >= B
+  unsigned long long pool_launches = 0;
+  int n_simds = 1024;              // CUs x 4 (hipDeviceProp_t::multiProcessorCount)
 };
 
 namespace {
+
+// ---- debug guard zones --------------------------------------------------------------------------
+// GPU AddressSanitizer is not available on this pool.  With RGS_DEBUG_GUARD_BYTES=<n> in the environment every
+// device buffer of a handle is allocated with n bytes of 0xA5 in front of and behind it; rgs_debug_check_guards()
+// reports the first buffer whose guard zone was written, and out-of-bounds READS land in mapped memory
+// instead of faulting, which tells an over-read from an over-write.  Off (n = 0) in normal use.
+size_t guard_bytes() {
+  static const size_t g = [] { const char *e = std::getenv("RGS_DEBUG_GUARD_BYTES"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+  return g;
+}
+
+template <typename T>
+hipError_t dev_alloc(rgs_sim *s, T **out, size_t bytes, const char *name) {
+  const size_t g = guard_bytes();
+  char *base = nullptr;
+  hipError_t e = hipMalloc((void **)&base, bytes + 2 * g);
+  if (e != hipSuccess) return e;
+  if (g) {
+    e = hipMemset(base, 0xA5, bytes + 2 * g);
+    if (e != hipSuccess) { (void)hipFree(base); return e; }
+  }
+  s->guards.push_back({name, base, bytes});
+  *out = (T *)(base + g);
+  return hipSuccess;
+}
+
+template <typename T>
+void dev_free(rgs_sim *s, T *&ptr) {
+  if (!ptr) return;
+  const size_t g = guard_bytes();
+  char *base = (char *)ptr - g;
+  for (size_t i = 0; i < s->guards.size(); ++i)
+    if (s->guards[i].base == base) { s->guards.erase(s->guards.begin() + i); break; }
+  (void)hipFree(base);
+  ptr = nullptr;
+}
 
 // div_tau<true>'s preconditions on the divisor (gsim_common.hpp): normal, moderate exponent,
 // significand not ending in a run of ones.
@@ -248,9 +295,9 @@ int noise_step(rgs_sim *s, StepArgs a) {
     const size_t need = (size_t)T * (size_t)B;
     if (need > s->tape_cap) {
       HIP_TRY(hipStreamSynchronize(s->stream));
-      hipFree(s->tape_dev);
+      dev_free(s, s->tape_dev);
       s->tape_dev = nullptr;
-      HIP_TRY(hipMalloc(&s->tape_dev, sizeof(double) * need));
+      HIP_TRY(dev_alloc(s, &s->tape_dev, sizeof(double) * need, "tape_dev"));
       s->tape_cap = need;
     }
     s->tape_host.resize(need);
@@ -394,13 +441,21 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     const size_t need = gsim_ops(s->n)->vgrid_doubles(s->B);   // velocity rows of every block's grids
     if (need > s->vgrid_cap) {
       HIP_TRY(hipStreamSynchronize(s->stream));
-      hipFree(s->vgrid);
+      dev_free(s, s->vgrid);
       s->vgrid = nullptr; s->vgrid_cap = 0;
-      HIP_TRY(hipMalloc(&s->vgrid, sizeof(double) * need));
+      HIP_TRY(dev_alloc(s, &s->vgrid, sizeof(double) * need, "vgrid"));
       s->vgrid_cap = need;
     }
     a.vgrid = s->vgrid;
     return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
+  }
+  if (variant == RGS_VARIANT_POOL && n_steps <= 65535 && s->B < (1ll << 26)) {
+    a.q_ctrl = s->q_ctrl; a.q_task = s->q_task; a.q_seq = s->q_seq; a.q_pending = s->q_pending;
+    a.q_mask = s->q_slots - 1;
+    s->pool_launches++;
+    a.q_done_target = s->pool_launches * (unsigned long long)((s->B + 63) / 64);
+    a.q_stay = ((s->B + 63) / 64) <= (long long)s->n_simds ? 1 : 0;
+    return launch_kind(s, a, LAUNCH_POOL, div_mode);
   }
   if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
   return launch_kind(s, a, LAUNCH_WAVE, !fast ? 0 : (s->one_step_ok ? 3 : 1));
@@ -415,6 +470,16 @@ int do_reset(rgs_sim *s, const double *x0_host, int batched) {
   hipError_t e = hipMemcpyAsync(x0_dev, x0_host, n * sizeof(double), hipMemcpyHostToDevice, s->stream);
   if (e == hipSuccess) e = gsim_ops(s->n)->reset(s->state, s->tcur, s->damage, x0_dev, batched, s->B, s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(s->counters, 0, (CNT_N + STAMP_N) * sizeof(unsigned long long), s->stream);
+#ifndef GSIM_NOQ
+  if (e == hipSuccess) e = hipMemsetAsync(s->q_ctrl, 0, sizeof(unsigned long long) * 8, s->stream);
+#endif
+#ifndef GSIM_NOQ
+  if (e == hipSuccess) e = hipMemsetAsync(s->q_seq, 0, sizeof(unsigned) * s->q_slots, s->stream);
+#endif
+#ifndef GSIM_NOQ
+  if (e == hipSuccess) e = hipMemsetAsync(s->q_pending, 0, sizeof(int) * (size_t)((s->B + 63) / 64), s->stream);
+#endif
+  s->pool_launches = 0;
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   hipFree(x0_dev);
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("reset: ") + hipGetErrorString(e));
@@ -440,6 +505,7 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(RGS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   rgs_sim *s = new rgs_sim();
+  s->n_simds = 4 * prop.multiProcessorCount;
   s->B = n_arenas;
   s->n = n_per_team;
   s->P = 2 * n_per_team;
@@ -449,13 +515,19 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&s->ev0);
   if (e == hipSuccess) e = hipEventCreate(&s->ev1);
-  if (e == hipSuccess) e = hipMalloc(&s->state, sizeof(double) * s->S * s->B);
-  if (e == hipSuccess) e = hipMalloc(&s->tcur, sizeof(double) * s->B);
-  if (e == hipSuccess) e = hipMalloc(&s->damage, sizeof(double) * s->P * s->P * s->B);
-  if (e == hipSuccess) e = hipMalloc(&s->tprev, sizeof(double) * s->B);
-  if (e == hipSuccess) e = hipMalloc(&s->ctl, sizeof(double) * s->P * 2 * s->B);
-  if (e == hipSuccess) e = hipMalloc(&s->counters, sizeof(unsigned long long) * (CNT_N + STAMP_N));
-  if (e == hipSuccess) e = hipMalloc(&s->flags, (size_t)s->B);
+  if (e == hipSuccess) e = dev_alloc(s, &s->state, sizeof(double) * s->S * s->B, "state");
+  if (e == hipSuccess) e = dev_alloc(s, &s->tcur, sizeof(double) * s->B, "tcur");
+  if (e == hipSuccess) e = dev_alloc(s, &s->damage, sizeof(double) * s->P * s->P * s->B, "damage");
+  if (e == hipSuccess) e = dev_alloc(s, &s->tprev, sizeof(double) * s->B, "tprev");
+  if (e == hipSuccess) e = dev_alloc(s, &s->ctl, sizeof(double) * s->P * 2 * s->B, "ctl");
+  if (e == hipSuccess) e = dev_alloc(s, &s->counters, sizeof(unsigned long long) * (CNT_N + STAMP_N), "counters");
+  if (e == hipSuccess) e = dev_alloc(s, &s->flags, (size_t)s->B, "flags");
+  s->q_slots = 64;
+  while (s->q_slots < (unsigned long long)s->B) s->q_slots <<= 1;
+  if (e == hipSuccess) e = dev_alloc(s, &s->q_ctrl, sizeof(unsigned long long) * 8, "q_ctrl");
+  if (e == hipSuccess) e = dev_alloc(s, &s->q_task, sizeof(unsigned long long) * s->q_slots, "q_task");
+  if (e == hipSuccess) e = dev_alloc(s, &s->q_seq, sizeof(unsigned) * s->q_slots, "q_seq");
+  if (e == hipSuccess) e = dev_alloc(s, &s->q_pending, sizeof(int) * (size_t)((s->B + 63) / 64), "q_pending");
   if (e != hipSuccess) {
     std::string m = std::string("rgs_create: ") + hipGetErrorString(e);
     rgs_destroy(s);
@@ -473,8 +545,9 @@ int rgs_destroy(rgs_sim *s) {
   if (!s) return RGS_OK;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  hipFree(s->state); hipFree(s->tcur); hipFree(s->tprev);
-  hipFree(s->vgrid); hipFree(s->tape_dev); hipFree(s->bak_state); hipFree(s->bak_tcur); hipFree(s->bak_damage); hipFree(s->consumed_dev); hipFree(s->bak_counters); hipFree(s->damage); hipFree(s->ctl); hipFree(s->counters); hipFree(s->flags);
+  dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
+  dev_free(s, s->q_ctrl); dev_free(s, s->q_task); dev_free(s, s->q_seq); dev_free(s, s->q_pending);
+  dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -490,11 +563,11 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
       return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 needs host-generated draw tapes and is limited to 4096 arenas per handle");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->bak_state) {
-      HIP_TRY(hipMalloc(&s->bak_state, sizeof(double) * s->S * s->B));
-      HIP_TRY(hipMalloc(&s->bak_tcur, sizeof(double) * s->B));
-      HIP_TRY(hipMalloc(&s->bak_damage, sizeof(double) * s->P * s->P * s->B));
-      HIP_TRY(hipMalloc(&s->consumed_dev, sizeof(int) * s->B));
-      HIP_TRY(hipMalloc(&s->bak_counters, sizeof(unsigned long long) * CNT_N));
+      HIP_TRY(dev_alloc(s, &s->bak_state, sizeof(double) * s->S * s->B, "bak_state"));
+      HIP_TRY(dev_alloc(s, &s->bak_tcur, sizeof(double) * s->B, "bak_tcur"));
+      HIP_TRY(dev_alloc(s, &s->bak_damage, sizeof(double) * s->P * s->P * s->B, "bak_damage"));
+      HIP_TRY(dev_alloc(s, &s->consumed_dev, sizeof(int) * s->B, "consumed_dev"));
+      HIP_TRY(dev_alloc(s, &s->bak_counters, sizeof(unsigned long long) * CNT_N, "bak_counters"));
     }
     s->reng.resize(s->B);
     s->wdist.resize(s->B, std::normal_distribution<double>(0.0, 1.0));   // kept across resets, cpp:41
@@ -632,7 +705,7 @@ int rgs_stream(rgs_sim *s, void **out) {
 int rgs_device_alloc(rgs_sim *s, int64_t n, double **out) {
   if (!s || !out || n < 1) return fail(RGS_ERR_ARG, "rgs_device_alloc: bad argument");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipMalloc(out, sizeof(double) * (size_t)n));
+  HIP_TRY(dev_alloc(s, out, sizeof(double) * (size_t)n, "rgs_device_alloc"));
   return RGS_OK;
 }
 
@@ -640,7 +713,7 @@ int rgs_device_free(rgs_sim *s, double *dev) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_device_free: null handle");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipFree(dev));
+  dev_free(s, dev);
   return RGS_OK;
 }
 
@@ -707,6 +780,7 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out8, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (out8[6] != 0) return fail(RGS_ERR_HIP, "pooled stepping kernel: a bounded wait timed out (internal protocol error); results are invalid");
   out8[7] = s->auto_wave ? 1 : 0;
   return RGS_OK;
 }
@@ -725,8 +799,31 @@ int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out17) {
   return RGS_OK;
 }
 
+// Debug (RGS_DEBUG_GUARD_BYTES=n): verifies the 0xA5 guard zones around every device buffer of the handle.
+int rgs_debug_check_guards(rgs_sim *s) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_debug_check_guards: null handle");
+  const size_t g = guard_bytes();
+  if (g == 0) return RGS_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<unsigned char> host(g);
+  for (const GuardedBuffer &b : s->guards) {
+    for (int side = 0; side < 2; ++side) {
+      const char *zone = side == 0 ? b.base : b.base + g + b.bytes;
+      HIP_TRY(hipMemcpy(host.data(), zone, g, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < g; ++i)
+        if (host[i] != 0xA5) {
+          const long long off = side == 0 ? (long long)i - (long long)g : (long long)(b.bytes + i);
+          return fail(RGS_ERR_HIP, std::string("guard zone of device buffer '") + b.name + "' (" + std::to_string(b.bytes) +
+                                       " bytes) overwritten at byte offset " + std::to_string(off));
+        }
+    }
+  }
+  return RGS_OK;
+}
+
 int rgs_set_variant(rgs_sim *s, int variant) {
-  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_HYBRID2) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
+  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_POOL) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
   return RGS_OK;
 }

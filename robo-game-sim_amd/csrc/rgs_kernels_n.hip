@@ -23,6 +23,19 @@ hipError_t launch_hybrid_mode(const StepArgs &args, hipStream_t stream) {
 }
 
 template <int MODE>
+hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
+#ifdef GSIM_NO_POOL
+  return hipErrorInvalidValue;
+#endif
+  const long long blocks = (args.B + 63) / 64;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
+#ifndef GSIM_NO_POOL
+  hipLaunchKernelGGL((k_step_pool<N, MODE>), dim3((unsigned)blocks), dim3(64), lds, stream, args);
+#endif
+  return hipGetLastError();
+}
+
+template <int MODE>
 hipError_t launch_hybrid2_mode(const StepArgs &args, hipStream_t stream) {
   constexpr bool SPLITV = Hybrid2Split<N>::value;
   const long long blocks = (args.B + 31) / 32;
@@ -51,6 +64,11 @@ hipError_t step(const StepArgs &args, hipStream_t stream, int kind, int mode) {
              : mode == DIV_PLAYER_POW2 ? launch_hybrid_mode<DIV_PLAYER_POW2>(args, stream)
              : mode == DIV_MARKSTEIN ? launch_hybrid_mode<DIV_MARKSTEIN>(args, stream)
                                      : launch_hybrid_mode<DIV_IEEE>(args, stream);
+    case LAUNCH_POOL:
+      return mode == DIV_POW2_ONESTEP ? launch_pool_mode<DIV_POW2_ONESTEP>(args, stream)
+             : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2>(args, stream)
+             : mode == DIV_MARKSTEIN ? launch_pool_mode<DIV_MARKSTEIN>(args, stream)
+                                     : launch_pool_mode<DIV_IEEE>(args, stream);
     case LAUNCH_HYBRID2:
       return mode == DIV_POW2_ONESTEP ? launch_hybrid2_mode<DIV_POW2_ONESTEP>(args, stream)
              : mode == DIV_PLAYER_POW2 ? launch_hybrid2_mode<DIV_PLAYER_POW2>(args, stream)

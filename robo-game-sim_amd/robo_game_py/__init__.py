@@ -17,7 +17,7 @@ import struct
 import numpy as np
 
 from . import _lib
-from ._lib import RgsError, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_WAVE  # noqa: F401
+from ._lib import RgsError, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_WAVE  # noqa: F401
 
 __all__ = ["GameSim", "BatchedGameSim", "SimStateView", "RgsError", "reset_arguments", "state_size",
            "log_record"]
@@ -320,6 +320,10 @@ class BatchedGameSim:
         return dict(zip(["lane_cycles", "wave_cycles", "rounds", "total_cycles", "g0_fill", "g0_scan0", "g0_events",
                          "g0_commit", "g0_arenas", "max_total_cycles", "max_wave_cycles", "max_rounds",
                          "max_event_loop_cycles", "ev_head", "ev_carry", "ev_scan", "ev_count"], list(out)))
+
+    def check_guards(self):
+        """Debug: raises if a device buffer's guard zone was overwritten (needs RGS_DEBUG_GUARD_BYTES in the environment)."""
+        _lib.check(self._L.rgs_debug_check_guards(self._h))
 
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))

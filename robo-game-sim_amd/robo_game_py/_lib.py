@@ -18,7 +18,7 @@ RGS_ERR_HIP = -2
 RGS_ERR_UNSUPPORTED = -3
 RGS_ERR_NO_DEVICE = -4
 
-VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2 = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL = 0, 1, 2, 3, 4
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -56,6 +56,7 @@ SIGNATURES = {
     "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
+    "rgs_debug_check_guards": (C.c_int, [_vp]),
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
     "rgs_set_fast_division": (C.c_int, [_vp, C.c_int]),
     "rgs_set_sparse_watch": (C.c_int, [_vp, C.c_int]),
