@@ -141,7 +141,8 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 template <int MODE, int M, int PKC, int C0 = 0>
 __device__ __forceinline__ void rk4_all_chains(double *p, double *v, const double *u, double tau_pl, double inv_pl,
                                                double tau_pk, double inv_pk, double h) {
-  constexpr int NB = (M + 9) / 10, SZ = (M + NB - 1) / NB;
+  constexpr int BATCH = GSIM_CHAIN_BATCH > 0 ? GSIM_CHAIN_BATCH : 10;
+  constexpr int NB = (M + BATCH - 1) / BATCH, SZ = (M + NB - 1) / NB;
   constexpr int MB = (M - C0) < SZ ? (M - C0) : SZ;
   rk4_chains<MODE, C0, MB, PKC>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);
   if constexpr (C0 + MB < M) rk4_all_chains<MODE, M, PKC, C0 + MB>(p, v, u, tau_pl, inv_pl, tau_pk, inv_pk, h);

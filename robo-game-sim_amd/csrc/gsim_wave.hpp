@@ -123,7 +123,12 @@ struct GridView {
       g = 0; e = 0; ax = 0;
     }
 #endif
-    if (SPLITV) return gv[g * (2 * E) + 2 * e + ax];
+    if (SPLITV) {
+      // gv is a raw global pointer: whatever reaches here is kept inside this group's region (LDS accesses
+      // out of range are dropped by the hardware, global ones fault the device)
+      const int gg = g < 0 ? 0 : (g > kGrid ? kGrid : g), ee = e < 0 ? 0 : (e >= E ? E - 1 : e);
+      return gv[gg * (2 * E) + 2 * ee + (ax & 1)];
+    }
     return lds[g * CS + 4 * e + 2 + ax];
   }
   __device__ __forceinline__ double &ctl(int e, int ax) const { return lds[U_OFF + 2 * e + ax]; }
@@ -225,18 +230,38 @@ template <int N, bool SPLITV>
 __device__ __forceinline__ unsigned column_flags(const StepArgs &p, const GridView<N, SPLITV> &G, int g, unsigned consider) {
   constexpr int E = 2 * N + 1, PK = 2 * N;
   unsigned fl = 0u;
+  if constexpr (N <= 4) {                                    // small teams: straight-line code over one batch of LDS loads
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if (N >= 4 && !((consider >> e) & 1u)) continue;         // large teams: skip the loads of unflagged discs
-    const double rad = disc_radius<N>(e);
-    const double px = G.pos(g, e, 0), py = G.pos(g, e, 1);
-    const bool wall = (py + rad >= kY / 2.0) | (py - rad <= -kY / 2.0) | (px + rad >= kX / 2.0) | (px - rad <= -kX / 2.0);
-    fl |= wall ? (1u << e) : 0u;
+    for (int e = 0; e < E; ++e) {
+      if (N >= 4 && !((consider >> e) & 1u)) continue;       // skip the loads of unflagged discs
+      const double rad = disc_radius<N>(e);
+      const double px = G.pos(g, e, 0), py = G.pos(g, e, 1);
+      const bool wall = (py + rad >= kY / 2.0) | (py - rad <= -kY / 2.0) | (px + rad >= kX / 2.0) | (px - rad <= -kX / 2.0);
+      fl |= wall ? (1u << e) : 0u;
 #pragma unroll
-    for (int o = e + 1; o < E; ++o) {
-      const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
-      const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
-      fl |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
+      for (int o = e + 1; o < E; ++o) {
+        const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
+        const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
+        fl |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
+      }
+    }
+  } else {                                                   // large teams (up to 105 pairs): loops over the flagged discs only,
+    unsigned todo = consider;                                // rolled -- unrolled, the pair tests of 7v7 alone are ~900 instructions
+    while (todo != 0u) {                                     // and pin more registers than the rest of the wave pass needs
+      const int e = __builtin_ctz(todo);
+      todo &= todo - 1u;
+      const double rad = e == PK ? kRPuck : kRPlayer;
+      const double px = G.pos(g, e, 0), py = G.pos(g, e, 1);
+      const bool wall = (py + rad >= kY / 2.0) | (py - rad <= -kY / 2.0) | (px + rad >= kX / 2.0) | (px - rad <= -kX / 2.0);
+      fl |= wall ? (1u << e) : 0u;
+      unsigned others = todo;                                // flagged discs after e
+      while (others != 0u) {
+        const int o = __builtin_ctz(others);
+        others &= others - 1u;
+        const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
+        const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
+        fl |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
+      }
     }
   }
   return fl & consider;
