@@ -104,8 +104,12 @@ int rgs_undecided(rgs_sim *sim, uint8_t *out_host);
 int rgs_get_damage(rgs_sim *sim, double *damage_host);
 int rgs_get_time(rgs_sim *sim, double *time_host);
 
-/* Extension: overwrite state and time of every arena; damage is zeroed. */
+/* Extension: overwrite state and time of every arena; damage is zeroed -- follow with
+ * rgs_set_damage to restore a checkpoint taken with rgs_get_state / rgs_get_time / rgs_get_damage.  The event
+ * counters are not part of a checkpoint, and with noise != 0 neither are the per-arena generators (a restored
+ * noisy game continues with the handle's current generator state, not the checkpoint's). */
 int rgs_set_state(rgs_sim *sim, const double *state_host, const double *time_host);
+int rgs_set_damage(rgs_sim *sim, const double *damage_host);   /* [P*P][B], layout of rgs_get_damage */
 
 /* Zero-copy access for device-side callers (torch tensors, RCCL all-gather). */
 int rgs_state_device_ptr(rgs_sim *sim, double **out_dev);   /* [S][B] */

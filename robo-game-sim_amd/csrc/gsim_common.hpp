@@ -105,37 +105,32 @@ struct StepArgs {
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]
-  // pooled kernel (k_step_pool): the chip-wide queue of flagged arena-steps.  q_ctrl[0] = tickets issued
-  // (tail), [1] = tickets claimed (head), [2] = wavefronts that have finished their steps (monotonic over
-  // launches: this launch is over at q_done_target); q_task[t & q_mask] = payload of ticket t, valid once
-  // q_seq[t & q_mask] == (unsigned)(t + 1); q_pending[w] = tasks of home wavefront w not yet completed.
-  unsigned long long *q_ctrl;
-  unsigned long long *q_task;
-  unsigned *q_seq;
-  int *q_pending;
-  unsigned long long q_mask;
-  unsigned long long q_done_target;
-  int q_stay;                        // 1: the grid fits the chip at once, finished wavefronts keep serving the queue
+  long long n_state, n_tcur, n_damage;   // element counts of state / tcur / damage (only the COH accessors use them)
 };
 
-// Global-memory accessors of the per-arena arrays (state, tcur, damage).  COH = false: plain loads and
-// stores -- an arena is only ever touched by the one wavefront that owns it for the whole launch.
-// COH = true (pooled kernel, gsim_kernels.hpp): arenas migrate between wavefronts on other CUs and
-// XCDs inside a launch, so every access is an agent-scope relaxed atomic, which the compiler emits as
-// an `sc1` (write-through / L1- and cross-XCD-L2-coherent) global access; the hand-over itself is
-// ordered by a vmcnt(0) drain and a flag or counter (MI355X_MICROARCH.md, "Valid forms", row 1 / 3).
+// Global-memory accessors of the per-arena arrays (state, tcur, damage).  Plain loads and stores: an arena is
+// only ever touched by wavefronts of ONE workgroup (its owner, or in the pooled kernel a sibling on the same CU
+// behind workgroup-scope fences).  COH = true is the sc1 (write-through, cross-XCD coherent) form a chip-wide
+// hand-over would need; it is kept for experiments and not instantiated by the shipped kernels.
+typedef unsigned int gsim_v2u __attribute__((ext_vector_type(2)));
+constexpr int kAuxSc1 = 16;                                  // cache-policy bits of the raw buffer builtins: sc1
+
 template <bool COH>
-__device__ __forceinline__ double gld(const double *q) {
-  if (COH)
-    return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  return *q;
+__device__ __forceinline__ double gld_at(const double *base, long long idx, long long count) {
+  if (COH) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(count * 8), 0x00020000);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(idx * 8), 0, kAuxSc1));
+  }
+  return base[idx];
 }
 template <bool COH>
-__device__ __forceinline__ void gst(double *q, double v) {
-  if (COH)
-    __hip_atomic_store((unsigned long long *)q, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    *q = v;
+__device__ __forceinline__ void gst_at(double *base, long long idx, long long count, double v) {
+  if (COH) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(count * 8), 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gsim_v2u, v), r, (int)(idx * 8), 0, kAuxSc1);
+  } else {
+    base[idx] = v;
+  }
 }
 
 // State-vector row of disc e's first component (include/SimState.h:14-23; players after the puck).
@@ -257,7 +252,7 @@ __device__ __forceinline__ void snapshot_state(const StepArgs &p, long long a, i
   if (p.traj == nullptr || (k0 + 1) % p.traj_every != 0) return;
   constexpr int S = 2 + 4 * (2 * N + 1);
   double *dst = p.traj + (long long)((k0 + 1) / p.traj_every - 1) * S * p.B;
-  for (int r = lane; r < S; r += nl) dst[(long long)r * p.B + a] = gld<COH>(&p.state[(long long)r * p.B + a]);
+  for (int r = lane; r < S; r += nl) dst[(long long)r * p.B + a] = gld_at<COH>(p.state, (long long)r * p.B + a, p.n_state);
 }
 
 // Orders LDS traffic between lanes of ONE wavefront: LDS operations of a wave

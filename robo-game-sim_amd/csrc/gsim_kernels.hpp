@@ -10,6 +10,16 @@ namespace gsim {
 
 constexpr int kWavesPerBlock = 4;
 
+// Register budget of the wave-per-arena kernel, as waves per SIMD (amdgpu_waves_per_eu): see DESIGN.md 3.1.
+#ifndef GSIM_WAVE_WAVES
+#define GSIM_WAVE_WAVES 0
+#endif
+#if GSIM_WAVE_WAVES > 0
+#define GSIM_WAVE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GSIM_WAVE_WAVES, GSIM_WAVE_WAVES)))
+#else
+#define GSIM_WAVE_OCCUPANCY
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Kernels
 // ---------------------------------------------------------------------------------------
@@ -17,7 +27,7 @@ constexpr int kWavesPerBlock = 4;
 // One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
 // the SoA arrays (L2-resident) between steps.
 template <int N, int GW, int FAST, bool NOISE = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave(StepArgs p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_step_wave(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
   constexpr int GPW = 64 / GW;
@@ -110,129 +120,121 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Pooled hybrid: the lane pass of k_step_hybrid, but the flagged arena-steps of ALL wavefronts go through
-// one chip-wide queue and every wavefront re-runs whatever it can claim from it.
+// Pooled hybrid: the lane pass of k_step_hybrid, four wavefronts (one per SIMD of a CU) per workgroup, and
+// the flagged arena-steps of the workgroup's 256 arenas go through ONE queue in LDS from which each of the
+// four wavefronts claims full rounds.
 //
-// Why.  With one wavefront per SIMD (65 536 arenas = 1024 wavefronts) a launch of k_step_hybrid ends with
-// its slowest wavefront, and what makes a wavefront slow is the number of wave-pass rounds its own 64
-// arenas need (C2, first 25 steps: 17 rounds on average, 40 at most; 1000 steps: 790 / 949) -- rounds that
-// mostly run with one or two of their GPW lane groups filled, because a wavefront can only pair up arenas
-// it owns.  Here a flagged arena-step is a task (arena, step, disc mask) that any wavefront may run: the
-// rounds are full (GPW arenas side by side, they cost the same as a round with one), a wavefront with
-// many flagged arenas is helped by those with none, and wavefronts that have finished their steps keep
-// serving the queue until the launch is over.  The arithmetic of a task is arena_step_group, unchanged.
+// Why.  In k_step_hybrid a wavefront can only pair up arenas it owns, so most wave-pass rounds run with one or
+// two of their GPW lane groups filled (C2: 1.9 arenas per round; a round costs the same with one arena as with
+// four), and a wavefront with many flagged arenas makes its 63 other arenas wait while its three neighbours on
+// the CU idle or run half-empty rounds of their own.  Pooled over 256 arenas the rounds fill up (C2, 25 steps:
+// 17 414 rounds -> about half), the four wavefronts share them, and a wavefront that has finished its steps
+// keeps serving its siblings.  The arithmetic of a task is arena_step_group, unchanged.
 //
-// Protocol (all of it agent scope; every access to state / tcur / damage is an sc1 access, gld / gst):
-//   home wavefront, step k:  lane pass; n = flagged lanes.  If n: drain its stores, q_pending[w] = n,
-//     reserve n tickets (atomic add on the tail), write the payloads, drain, publish q_seq[slot] = t + 1.
-//     Then claim and run rounds until q_pending[w] is 0 again (somebody -- possibly itself -- has run
-//     each of its tasks); a wavefront with n = 0 lends at most one round per step.
-//   any wavefront, one round: claim up to GPW consecutive tickets by CAS on the head; lane group g waits
-//     for q_seq of ticket h + g, reads the payload, runs arena_step_group for that arena at that step,
-//     drains its stores and decrements q_pending of the arena's home wavefront.
-//   An arena is owned by exactly one wavefront at any time: its home between steps, the claimer of its
-//     ticket while the task runs; the home does not touch it again before q_pending[w] reads 0.
-//   Progress: a wavefront never waits while the queue holds an unclaimed ticket (it claims it), a claimed
-//     ticket is being run by a live wavefront, and nobody depends on a finished wavefront staying, so
-//     every wait is bounded by one round.
-// Tickets and q_ctrl[2] are monotonic over the launches of a handle (no per-launch reset); the ring has
-// at least B slots, and at most one task per arena is outstanding.
+// A chip-wide queue in global memory (all 1024 wavefronts) was built first and measured: device-scope atomics
+// on one hot address cost ~1 us each across the eight XCDs and serialise, 4 ms per step.  LDS atomics cost
+// ~100 cycles, and everything a workgroup shares stays inside one CU: the hand-over of an arena's state
+// between two of its wavefronts needs workgroup-scope fences only (same L1, same L2).
+//
+// Protocol (workgroup scope):
+//   home wavefront, step k:  lane pass; n = flagged lanes.  If n: release fence (its stores of step k-1 are
+//     done), pend[w] = n, reserve n tickets (atomic add on tail), write the payloads, then seq[slot] = t + 1.
+//     Then claim and run rounds until pend[w] is 0 again; a wavefront with n = 0 lends at most one round.
+//   any wavefront, one round: claim up to GPW consecutive tickets by CAS on head; lane group g waits for
+//     seq of ticket h + g, reads the payload, acquire fence, runs arena_step_group for that arena at that
+//     step, release fence, decrements pend of the arena's home wavefront.
+//   An arena is owned by exactly one wavefront at any time: its home between steps, the claimer while its
+//     task runs; the home does not touch it again before pend[w] reads 0 (+ acquire fence).
+//   Progress: the four wavefronts of a workgroup are resident together by construction; a wavefront never
+//     waits while the queue holds an unclaimed ticket, and a claimed ticket is being run.  Spins are
+//     bounded anyway (kPoolSpinLimit) and a timeout is reported as an error by the host.
 // ---------------------------------------------------------------------------------------
-// Every spin is bounded (a protocol error must not hang the GPU): ~2^22 polls of >= 64 cycles, i.e. > 0.1 s,
-// four orders of magnitude above any legitimate wait; a timeout is counted and reported by the host as an error.
-constexpr int kPoolSpinLimit = 1 << 22;
+constexpr int kPoolWaves = 4;                                // wavefronts per workgroup = SIMDs per CU
+constexpr int kPoolSlots = 256;                              // ring: one slot per arena of the workgroup
+constexpr int kPoolSpinLimit = 1 << 24;                      // polls of >= 64 cycles: > 0.4 s, far above any legitimate wait
 
-#ifndef GSIM_POOL_FENCES
-#define GSIM_POOL_FENCES 1
-#endif
+struct PoolQueue {                                           // lives in LDS behind the grids
+  unsigned tail, head, done, pad;
+  int pend[kPoolWaves];
+  unsigned seq[kPoolSlots];
+  unsigned long long task[kPoolSlots];
+};
 
-__device__ __forceinline__ void pool_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void pool_release() {             // stores of this wavefront visible chip-wide before what follows
-  pool_drain();
-  if (GSIM_POOL_FENCES) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    pool_drain();
-  }
-}
-__device__ __forceinline__ void pool_acquire() {             // after a matched poll, before loading what it guards
-  if (GSIM_POOL_FENCES) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    pool_drain();
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ unsigned long long pool_ld(const unsigned long long *q) {
-  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned pool_ld(const unsigned *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int pool_ld(const int *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T lds_ld(const T *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
-// payload: arena (26 bits) | step within the launch (16) | discs whose watch fired (16) | first column (6)
-__device__ __forceinline__ unsigned long long pool_pack(long long a, int k, unsigned discmask) {
-  return (unsigned long long)a | ((unsigned long long)(unsigned)k << 26) | ((unsigned long long)(discmask & 0xFFFFu) << 42) |
-         ((unsigned long long)((discmask >> 16) & 63u) << 58);
+// payload: arena index inside the workgroup (8 bits) | step within the launch (26) | discs (16) | first column (6)
+__device__ __forceinline__ unsigned long long pool_pack(int local, int k, unsigned discmask) {
+  return (unsigned long long)(unsigned)local | ((unsigned long long)(unsigned)k << 8) | ((unsigned long long)(discmask & 0xFFFFu) << 34) |
+         ((unsigned long long)((discmask >> 16) & 63u) << 50);
 }
 
 // One round: claims up to GPW tickets and runs them.  Returns false when the queue had nothing to claim.
 template <int N, int FAST>
-__device__ __forceinline__ bool pool_round(const StepArgs &p, const GridView<N, false> &G, int lane, int grp, int lg) {
+__device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, const GridView<N, false> &G, long long wg_a0, int lane,
+                                           int grp, int lg) {
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
-  unsigned long long h = 0ull;
+  unsigned h = 0u;
   int take = 0;
   if (lane == 0) {
     for (int tries = 0; tries < 8 && take == 0; ++tries) {
-      h = pool_ld(&p.q_ctrl[1]);
-      const long long avail = (long long)(pool_ld(&p.q_ctrl[0]) - h);
+      h = lds_ld(&Q->head);
+      const int avail = (int)(lds_ld(&Q->tail) - h);
       if (avail <= 0) break;
-      const int want = avail < GPW ? (int)avail : GPW;
-      unsigned long long expect = h;
-      if (__hip_atomic_compare_exchange_strong(&p.q_ctrl[1], &expect, h + (unsigned long long)want, __ATOMIC_RELAXED,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      const int want = avail < GPW ? avail : GPW;
+      unsigned expect = h;
+      if (__hip_atomic_compare_exchange_strong(&Q->head, &expect, h + (unsigned)want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP))
         take = want;
     }
   }
-  h = __shfl(h, 0);
+  h = (unsigned)__shfl((int)h, 0);
   take = __shfl(take, 0);
   if (take == 0) return false;
   unsigned long long payload = 0ull;
   if (grp < take) {
-    const unsigned long long t = h + (unsigned long long)grp;
-    const unsigned long long slot = t & p.q_mask;
+    const unsigned t = h + (unsigned)grp;
+    const unsigned slot = t & (kPoolSlots - 1);
     if (lg == 0) {
-      int spins = 0;                                         // the producer is between its ticket and its publish: a few hundred cycles
-      while (pool_ld(&p.q_seq[slot]) != (unsigned)(t + 1ull)) {
+      int spins = 0;                                         // the producer is between its ticket and its publish
+      while (lds_ld(&Q->seq[slot]) != t + 1u) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kPoolSpinLimit) { atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
       }
-      payload = pool_ld(&p.q_task[slot]);
+      payload = lds_ld(&Q->task[slot]);
     }
     payload = __shfl(payload, lane - lg);
   }
-  const long long arena = (long long)(payload & ((1ull << 26) - 1ull));
-  pool_acquire();                                            // the arenas' state, written by other wavefronts
+  const int local = (int)(payload & 255ull);
+  wg_acquire();                                              // the arenas' state, written by the other wavefronts of this CU
   if (grp < take) {
-    const int kk = (int)((payload >> 26) & 0xFFFFull);
-    const unsigned dm = (unsigned)((payload >> 42) & 0xFFFFull) | ((unsigned)((payload >> 58) & 63ull) << 16);
-    arena_step_group<N, GW, FAST, false, false, true>(p, p.ctl + (long long)kk * p.ctl_stride, arena, G, lg, lane - lg, dm);
+    const int kk = (int)((payload >> 8) & 0x3FFFFFFull);
+    const unsigned dm = (unsigned)((payload >> 34) & 0xFFFFull) | ((unsigned)((payload >> 50) & 63ull) << 16);
+    arena_step_group<N, GW, FAST, false, false>(p, p.ctl + (long long)kk * p.ctl_stride, wg_a0 + local, G, lg, lane - lg, dm);
   }
-  pool_release();                                            // results written through before the home wavefront is told
-  if (grp < take && lg == 0) __hip_atomic_fetch_add(&p.q_pending[arena >> 6], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wg_release();                                              // results stored before the home wavefront is told
+  if (grp < take && lg == 0) __hip_atomic_fetch_add(&Q->pend[local >> 6], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return true;
 }
 
 template <int N, int MODE>
-__global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_pool(StepArgs p) {
+__global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
-  constexpr int GW = HybridGroups<N>::GW;
-  const int lane = threadIdx.x;
+  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / GW, lg = lane % GW;
-  const long long a0 = (long long)blockIdx.x * 64;
-  const long long a = a0 + lane;
+  const long long wg_a0 = (long long)blockIdx.x * (64 * kPoolWaves);
+  const long long a = wg_a0 + threadIdx.x;
   const bool mine = a < p.B;
-  const GridView<N, false> G{lds + grp * WaveLayout<N>::DOUBLES, nullptr GSIM_GRID_DBG(p)};
-  int *my_pending = p.q_pending + blockIdx.x;
-  const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
+  const GridView<N, false> G{lds + (wave * GPW + grp) * WaveLayout<N>::DOUBLES, nullptr GSIM_GRID_DBG(p)};
+  PoolQueue *Q = (PoolQueue *)(lds + kPoolWaves * GPW * WaveLayout<N>::DOUBLES);
+  if (threadIdx.x < kPoolSlots) Q->seq[threadIdx.x] = 0u;
+  if (threadIdx.x < kPoolWaves) Q->pend[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { Q->tail = 0u; Q->head = 0u; Q->done = 0u; }
+  __syncthreads();
   unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
   if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
   for (int k = 0; k < p.n_steps; ++k) {
@@ -240,61 +242,56 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_pool(StepArgs p) {
     unsigned discmask = 0u;
     unsigned long long t0 = 0, t1 = 0;
     if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
-    const bool slow = mine && lane_step<N, MODE, true>(p, ctl, a, discmask);
+    const bool slow = mine && lane_step<N, MODE>(p, ctl, a, discmask);
     const unsigned long long m = __ballot(slow);
     const int n = __builtin_popcountll(m);
     if (n != 0) {
-      pool_release();                                        // these arenas' state as of step k is out before they are offered
-      unsigned long long tk = 0ull;
+      wg_release();                                          // these arenas' state as of step k is stored before they are offered
+      unsigned tk = 0u;
       if (lane == 0) {
         atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)n);
-        __hip_atomic_store(my_pending, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tk = __hip_atomic_fetch_add(&p.q_ctrl[0], (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&Q->pend[wave], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tk = __hip_atomic_fetch_add(&Q->tail, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      tk = __shfl(tk, 0) + (unsigned long long)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-      if (slow) __hip_atomic_store(&p.q_task[tk & p.q_mask], pool_pack(a, k, discmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pool_drain();                                          // payloads (and q_pending) before the tickets become readable
-      if (slow) __hip_atomic_store(&p.q_seq[tk & p.q_mask], (unsigned)(tk + 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tk = (unsigned)__shfl((int)tk, 0) + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (slow) {
+        __hip_atomic_store(&Q->task[tk & (kPoolSlots - 1)], pool_pack((int)threadIdx.x, k, discmask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&Q->seq[tk & (kPoolSlots - 1)], tk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
     if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
     int waits = 0;
     for (int lent = 0;;) {                                   // serve the queue
       int pend = 0;
       if (n != 0) {
-        if (lane == 0) pend = pool_ld(my_pending);
+        if (lane == 0) pend = lds_ld(&Q->pend[wave]);
         pend = __shfl(pend, 0);
         if (pend == 0) break;                                // every task of this wavefront's arenas has been run
       } else if (lent != 0) {
         break;                                               // nothing of its own: one round lent per step
       }
-      if (pool_round<N, FAST>(p, G, lane, grp, lg)) { lent = 1; n_rounds++; }
+      if (pool_round<N, FAST>(p, Q, G, wg_a0, lane, grp, lg)) { lent = 1; n_rounds++; }
       else if (n == 0) break;
-      else {                                                 // its remaining tasks are running elsewhere: at most one round's time
-        __builtin_amdgcn_s_sleep(2);
+      else {                                                 // its remaining tasks are running on a sibling: at most one round's time
+        __builtin_amdgcn_s_sleep(4);
         if (++waits > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
       }
     }
-    if (n != 0) pool_acquire();                              // results of its arenas, written by whoever ran them
+    if (n != 0) wg_acquire();                                // results of its arenas, stored by whoever ran them
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
-    if (mine) snapshot_state<N, true>(p, a, k, 0, 1);
+    if (mine) snapshot_state<N>(p, a, k, 0, 1);
   }
-  // This wavefront's arenas are done.  If the whole grid is resident at once (q_stay, set by the host when
-  // there are no more wavefronts than SIMDs) it keeps serving the queue until every wavefront has finished
-  // its steps -- that is what evens out the end of the launch.  Nobody depends on it staying (a wavefront
-  // whose tasks nobody claims runs them itself), so the wait is bounded in time as well: should the grid
-  // not be resident after all (another process on the GPU), it leaves after a quarter of its own run time.
-  if (lane == 0) __hip_atomic_fetch_add(&p.q_ctrl[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (p.q_stay) {
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    const unsigned long long patience = (t_start - t_launch) / 4 + 2000000ull;
-    for (;;) {
-      if (pool_round<N, FAST>(p, G, lane, grp, lg)) { n_rounds++; continue; }
-      unsigned long long done = 0ull;
-      if (lane == 0) done = pool_ld(&p.q_ctrl[2]);
-      done = __shfl(done, 0);
-      if (done >= p.q_done_target || __builtin_amdgcn_s_memtime() - t_start > patience) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
+  // this wavefront's arenas are done; keep serving its siblings until all four are (they are resident: bounded)
+  if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int waits = 0;;) {
+    if (pool_round<N, FAST>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; continue; }
+    unsigned done = 0u;
+    if (lane == 0) done = lds_ld(&Q->done);
+    done = (unsigned)__shfl((int)done, 0);
+    if (done >= (unsigned)kPoolWaves) break;
+    __builtin_amdgcn_s_sleep(8);
+    if (++waits > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
   }
   if (GSIM_STAMPS && p.stamps && lane == 0) {
     const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;

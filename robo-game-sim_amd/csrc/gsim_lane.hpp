@@ -156,17 +156,17 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
                                           unsigned &discmask) {
   constexpr int P = 2 * N, E = P + 1, PK = P, M = 2 * E;
   const long long B = p.B;
-  const double TAS = gld<COH>(&p.state[0 * B + a]), TBS = gld<COH>(&p.state[1 * B + a]);
+  const double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
   if (!(TAS < p.win && TBS < p.win)) return false;          // decided: run() is a no-op, cpp:121-123
 
   double pos[M], vel[M], u[M];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int row = state_row<N>(e);
-    pos[2 * e + 0] = gld<COH>(&p.state[(long long)(row + 0) * B + a]);
-    pos[2 * e + 1] = gld<COH>(&p.state[(long long)(row + 1) * B + a]);
-    vel[2 * e + 0] = gld<COH>(&p.state[(long long)(row + 2) * B + a]);
-    vel[2 * e + 1] = gld<COH>(&p.state[(long long)(row + 3) * B + a]);
+    pos[2 * e + 0] = gld_at<COH>(p.state, (long long)(row + 0) * B + a, p.n_state);
+    pos[2 * e + 1] = gld_at<COH>(p.state, (long long)(row + 1) * B + a, p.n_state);
+    vel[2 * e + 0] = gld_at<COH>(p.state, (long long)(row + 2) * B + a, p.n_state);
+    vel[2 * e + 1] = gld_at<COH>(p.state, (long long)(row + 3) * B + a, p.n_state);
     if (e != PK) {
       u[2 * e + 0] = ctl[(long long)(2 * e + 0) * B + a];
       u[2 * e + 1] = ctl[(long long)(2 * e + 1) * B + a];
@@ -277,12 +277,12 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
 #pragma unroll
   for (int e = 0; e < E; ++e) {                             // cpp:153-157
     const int row = state_row<N>(e);
-    gst<COH>(&p.state[(long long)(row + 0) * B + a], pos[2 * e + 0]);
-    gst<COH>(&p.state[(long long)(row + 1) * B + a], pos[2 * e + 1]);
-    gst<COH>(&p.state[(long long)(row + 2) * B + a], vel[2 * e + 0]);
-    gst<COH>(&p.state[(long long)(row + 3) * B + a], vel[2 * e + 1]);
+    gst_at<COH>(p.state, (long long)(row + 0) * B + a, p.n_state, pos[2 * e + 0]);
+    gst_at<COH>(p.state, (long long)(row + 1) * B + a, p.n_state, pos[2 * e + 1]);
+    gst_at<COH>(p.state, (long long)(row + 2) * B + a, p.n_state, vel[2 * e + 0]);
+    gst_at<COH>(p.state, (long long)(row + 3) * B + a, p.n_state, vel[2 * e + 1]);
   }
-  gst<COH>(&p.tcur[a], gld<COH>(&p.tcur[a]) + p.dt);                             // cpp:158
+  gst_at<COH>(p.tcur, a, p.n_tcur, gld_at<COH>(p.tcur, a, p.n_tcur) + p.dt);                             // cpp:158
   return false;
 }
 
@@ -303,15 +303,15 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
                                                 unsigned &discmask) {
   constexpr int P = 2 * N, E = P + 1, PK = P;
   const long long B = p.B;
-  const double TAS = gld<COH>(&p.state[0 * B + a]), TBS = gld<COH>(&p.state[1 * B + a]);
+  const double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
   if (!(TAS < p.win && TBS < p.win)) return false;          // decided (both lanes of the arena agree)
 
   double pos[E], vel[E], u[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int row = state_row<N>(e);
-    pos[e] = gld<COH>(&p.state[(long long)(row + ax) * B + a]);
-    vel[e] = gld<COH>(&p.state[(long long)(row + 2 + ax) * B + a]);
+    pos[e] = gld_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state);
+    vel[e] = gld_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state);
     u[e] = e != PK ? ctl[(long long)(2 * e + ax) * B + a] : 0.0;   // cpp:188
   }
   const double dt_col = p.dt_col;
@@ -398,10 +398,10 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
 #pragma unroll
   for (int e = 0; e < E; ++e) {                             // cpp:153-157, this lane's axis
     const int row = state_row<N>(e);
-    gst<COH>(&p.state[(long long)(row + ax) * B + a], pos[e]);
-    gst<COH>(&p.state[(long long)(row + 2 + ax) * B + a], vel[e]);
+    gst_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state, pos[e]);
+    gst_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state, vel[e]);
   }
-  if (ax == 0) gst<COH>(&p.tcur[a], gld<COH>(&p.tcur[a]) + p.dt);                // cpp:158
+  if (ax == 0) gst_at<COH>(p.tcur, a, p.n_tcur, gld_at<COH>(p.tcur, a, p.n_tcur) + p.dt);                // cpp:158
   return false;
 }
 

@@ -334,10 +334,21 @@ struct EventSlots {
 template <int N>
 struct EventLane {
   int d, ax;
-  bool first, is_pair, my_axis, positive_wall, store;
-  double u, coef, tau, inv, r_own, rsum, lt, wall;
-  double push101, push11;    // ((1.01*r_own)/(ri+rj)), ((1.1*r_own)/(ri+rj)): cpp:263-264, 588-589 (host-computed quotients)
-  double mass_ratio;         // (2*m_other)/(mi+mj), cpp:273-274
+  bool first, is_pair, my_axis, positive_wall, store, own_puck, with_puck, vertical;
+  double u;
+  // Everything else is a choice between a few per-batch constants (scalar registers): selected where it is used
+  // instead of being carried in vector registers through the event loop (the wave-per-arena kernel's budget).
+  __device__ __forceinline__ double coef() const { return own_puck ? 0.2 : 1.0; }
+  __device__ __forceinline__ double tau(const StepArgs &p) const { return own_puck ? p.tau_puck : p.tau_player; }
+  __device__ __forceinline__ double inv(const StepArgs &p) const { return own_puck ? p.inv_tau_puck : p.inv_tau_player; }
+  __device__ __forceinline__ double r_own() const { return own_puck ? kRPuck : kRPlayer; }
+  __device__ __forceinline__ double rsum() const { return with_puck ? kRPlayer + kRPuck : kRPlayer + kRPlayer; }   // ri + rj
+  __device__ __forceinline__ double lt(const StepArgs &p) const { return with_puck ? p.lt_pk : p.lt_pp; }   // s <= lt  <=>  rsum - sqrt(s) > 0
+  __device__ __forceinline__ double wall() const { return vertical ? kY / 2.0 : kX / 2.0; }
+  // ((1.01*r_own)/(ri+rj)), ((1.1*r_own)/(ri+rj)): cpp:263-264, 588-589; (2*m_other)/(mi+mj): cpp:273-274 (host-computed quotients)
+  __device__ __forceinline__ double push101(const StepArgs &p) const { return !with_puck ? p.push101_pp : (own_puck ? p.push101_pkk : p.push101_plk); }
+  __device__ __forceinline__ double push11(const StepArgs &p) const { return !with_puck ? p.push11_pp : (own_puck ? p.push11_pkk : p.push11_plk); }
+  __device__ __forceinline__ double mass_ratio(const StepArgs &p) const { return !with_puck ? p.ratio_pp : (own_puck ? p.ratio_vs_player : p.ratio_vs_puck); }
 };
 
 template <int N, bool SPLITV>
@@ -350,20 +361,12 @@ __device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const Grid
   c.ax = lg & 1;
   c.d = (c.is_pair && !c.first) ? cj : ci;
   c.store = c.is_pair || c.first;
-  c.r_own = disc_radius<N>(c.d);
+  c.own_puck = c.d == PK;
+  c.with_puck = ci == PK || cj == PK;
   c.u = G.ctl(c.d, c.ax);
-  c.coef = c.d == PK ? 0.2 : 1.0;
-  c.tau = c.d == PK ? p.tau_puck : p.tau_player;
-  c.inv = c.d == PK ? p.inv_tau_puck : p.inv_tau_player;
-  const bool with_puck = ci == PK || cj == PK;
-  c.rsum = disc_radius<N>(ci) + disc_radius<N>(c.is_pair ? cj : ci);
-  c.lt = with_puck ? p.lt_pk : p.lt_pp;                      // s <= lt  <=>  rsum - sqrt(s) > 0
-  c.push101 = !with_puck ? p.push101_pp : (c.d == PK ? p.push101_pkk : p.push101_plk);
-  c.push11 = !with_puck ? p.push11_pp : (c.d == PK ? p.push11_pkk : p.push11_plk);
-  c.mass_ratio = !with_puck ? p.ratio_pp : (c.d == PK ? p.ratio_vs_player : p.ratio_vs_puck);
-  c.my_axis = (kind == UP || kind == DOWN) ? (c.ax == 1) : (c.ax == 0);
+  c.vertical = kind == UP || kind == DOWN;
+  c.my_axis = c.vertical ? (c.ax == 1) : (c.ax == 0);
   c.positive_wall = (kind == UP || kind == RIGHT);
-  c.wall = (kind == UP || kind == DOWN) ? kY / 2.0 : kX / 2.0;
   return c;
 }
 
@@ -371,19 +374,19 @@ __device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const Grid
 // into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).  Select-based: the
 // square root is taken whether or not the discs overlap.
 template <int N, bool SPLITV>
-__device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
+__device__ __forceinline__ void fix_store_column(const StepArgs &p, const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
                                                  bool wall_fix) {
   if (c.is_pair) {
     const double po = quad_xor2(x.p);
     const double pij = c.first ? po - x.p : x.p - po;
     const double sq = pij * pij;
     const double s = sq + quad_xor1(sq);
-    const double overlap = c.rsum - sqrt_ieee(s);
-    const double cc = (c.first ? -c.push11 : c.push11) * overlap;    // -(a*b) == (-a)*b exactly
+    const double overlap = c.rsum() - sqrt_ieee(s);
+    const double cc = (c.first ? -c.push11(p) : c.push11(p)) * overlap;    // -(a*b) == (-a)*b exactly
     const double moved = x.p + cc * pij;                             // x - c*pij == x + (-(c*pij))
-    x.p = (s <= c.lt) ? moved : x.p;
+    x.p = (s <= c.lt(p)) ? moved : x.p;
   } else if (c.my_axis && wall_fix) {
-    const double overlap = c.positive_wall ? (x.p + c.r_own - c.wall) : (-x.p + c.r_own - c.wall);
+    const double overlap = c.positive_wall ? (x.p + c.r_own() - c.wall()) : (-x.p + c.r_own() - c.wall());
     const double cc = 1.1 * overlap;
     const double moved = c.positive_wall ? x.p - cc : x.p + cc;
     x.p = (overlap > 0) ? moved : x.p;
@@ -406,8 +409,8 @@ __device__ __forceinline__ void finish_columns(const StepArgs &p, const GridView
     x.v = G.vel(from - 1, c.d, c.ax);
     const bool fast = FAST != 0 && fast_division_safe(c.u, x.v);
     for (int g = from; g <= to; ++g) {
-      x = rk4_dyn<FAST>(x, c.u, c.coef, c.tau, c.inv, dt_col, fast);
-      fix_store_column<N, SPLITV>(c, G, x, g, true);
+      x = rk4_dyn<FAST>(x, c.u, c.coef(), c.tau(p), c.inv(p), dt_col, fast);
+      fix_store_column<N, SPLITV>(p, c, G, x, g, true);
     }
   }
   grid_sync<SPLITV>();
@@ -475,9 +478,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   constexpr int E = L::E, PK = L::PK;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
   const long long B = p.B;
-  double TAS = gld<COH>(&p.state[0 * B + a]), TBS = gld<COH>(&p.state[1 * B + a]);
+  double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
   if (!(TAS < p.win && TBS < p.win)) return;                 // undecided(), cpp:57-60,121
-  const double t0 = gld<COH>(&p.tcur[a]);
+  const double t0 = gld_at<COH>(p.tcur, a, p.n_tcur);
   const double dt = p.dt, dt_col = p.dt_col;
   const double *tape = NOISE ? p.tape + a * (long long)p.tape_len : nullptr;
   const int tape_last = NOISE ? p.tape_len - 8 : 0;         // last legal start of an 8-draw record
@@ -491,8 +494,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
     Chain x;
-    x.p = gld<COH>(&p.state[(long long)(row + ax) * B + a]);
-    x.v = gld<COH>(&p.state[(long long)(row + 2 + ax) * B + a]);
+    x.p = gld_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state);
+    x.v = gld_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state);
     double u = 0.0, coef = 0.2, tau = p.tau_puck, inv = p.inv_tau_puck;   // cpp:188: puck input is (0, 0)
     if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; inv = p.inv_tau_player; }
     G.ctl(e, ax) = u;
@@ -624,10 +627,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       n_overflow += last_overflow ? (unsigned)reps : 0u;
       if (is_pair && ci != PK && cj != PK && lg == 0) {       // cpp:277-282, one rounding per iteration like the reference
         constexpr int Pn = L::P;
-        double dij = gld<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a]), dji = gld<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a]);
+        double dij = gld_at<COH>(p.damage, (long long)(ci * Pn + cj) * B + a, p.n_damage), dji = gld_at<COH>(p.damage, (long long)(cj * Pn + ci) * B + a, p.n_damage);
         for (int r = 0; r < reps; ++r) { dij += last_damage; dji += last_damage; }
-        gst<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a], dij);
-        gst<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a], dji);
+        gst_at<COH>(p.damage, (long long)(ci * Pn + cj) * B + a, p.n_damage, dij);
+        gst_at<COH>(p.damage, (long long)(cj * Pn + ci) * B + a, p.n_damage, dji);
       }
       counter = kLoopCap;
       ev.put(ci, ct, cj, ckind, seq++);                      // the list is not empty when the cap ends the loop
@@ -666,14 +669,14 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     auto noisy = [&](Chain xx, double hh) {
       const int c0 = cur + 8 * (call * np + slot);
       ++call;
-      return rk4_axis_noise(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax);
+      return rk4_axis_noise(xx, el.u, el.coef(), el.tau(p), hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax);
     };
     if (lg < 4) {
       x.p = G.pos(base - 1, el.d, el.ax);
       x.v = G.vel(base - 1, el.d, el.ax);
       fast = FAST != 0 && fast_division_safe(el.u, x.v);
       if (NOISE) x = noisy(x, dt_t); else
-      x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_t, fast);   // cpp:255-256, 309
+      x = rk4_dyn<FAST>(x, el.u, el.coef(), el.tau(p), el.inv(p), dt_t, fast);   // cpp:255-256, 309
 
       if (is_pair) {                                         // cpp:242-282
         {                                                    // cpp:259-265 (pij not normalised)
@@ -681,10 +684,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           const double pij = el.first ? po - x.p : x.p - po;
           const double sq = pij * pij;
           const double s = sq + quad_xor1(sq);
-          const double overlap = el.rsum - sqrt_ieee(s);
-          const double c = (el.first ? -el.push101 : el.push101) * overlap;   // ((1.01*r)/(ri+rj))*overlap, sign of the push
+          const double overlap = el.rsum() - sqrt_ieee(s);
+          const double c = (el.first ? -el.push101(p) : el.push101(p)) * overlap;   // ((1.01*r)/(ri+rj))*overlap, sign of the push
           const double moved = x.p + c * pij;                // x - c*pij == x + (-c)*pij exactly
-          x.p = (s <= el.lt) ? moved : x.p;                  // only if overlap > 0
+          x.p = (s <= el.lt(p)) ? moved : x.p;                  // only if overlap > 0
         }
         {                                                    // elastic impulse, cpp:268-274
           const double po = quad_xor2(x.p), vo = quad_xor2(x.v);
@@ -692,15 +695,15 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           const double pr = dv * dp, sq = dp * dp;
           const double dot1 = pr + quad_xor1(pr);
           const double dot2 = sq + quad_xor1(sq);
-          const double s = div_ieee(el.mass_ratio * dot1, dot2);   // ((2*m_other)/(mi+mj))*dot1/dot2
+          const double s = div_ieee(el.mass_ratio(p) * dot1, dot2);   // ((2*m_other)/(mi+mj))*dot1/dot2
           if (ci != PK && cj != PK) {                        // damage, cpp:277-282
             const double dvsq = dv * dv;
             const double dv_sq = 0.01 * (dvsq + quad_xor1(dvsq));
             last_damage = p.m_player * dv_sq;                // lane 0 of the group keeps it for the fixed-point shortcut
             if (lg == 0) {
               constexpr int Pn = L::P;
-              gst<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a], gld<COH>(&p.damage[(long long)(ci * Pn + cj) * B + a]) + last_damage);
-              gst<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a], gld<COH>(&p.damage[(long long)(cj * Pn + ci) * B + a]) + last_damage);
+              gst_at<COH>(p.damage, (long long)(ci * Pn + cj) * B + a, p.n_damage, gld_at<COH>(p.damage, (long long)(ci * Pn + cj) * B + a, p.n_damage) + last_damage);
+              gst_at<COH>(p.damage, (long long)(cj * Pn + ci) * B + a, p.n_damage, gld_at<COH>(p.damage, (long long)(cj * Pn + ci) * B + a, p.n_damage) + last_damage);
             }
           }
           x.v = x.v - s * dp;
@@ -717,9 +720,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       } else if (NOISE) {
         x = noisy(x, dt_col - dt_t);
       } else {
-        x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col - dt_t, fast);   // cpp:287-288, 331
+        x = rk4_dyn<FAST>(x, el.u, el.coef(), el.tau(p), el.inv(p), dt_col - dt_t, fast);   // cpp:287-288, 331
       }
-      fix_store_column<N, SPLITV>(el, G, x, base, !goal);    // cpp:289, 332 (no wall push after a goal, cpp:324-327)
+      fix_store_column<N, SPLITV>(p, el, G, x, base, !goal);    // cpp:289, 332 (no wall push after a goal, cpp:324-327)
     }
     goal = __shfl(goal ? 1 : 0, gbase) != 0;
     if (goal) {                                              // cpp:324-326
@@ -740,7 +743,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       if (lg < 4) {
         for (int g = base + 1; g <= kGrid; ++g) {
           x = noisy(x, dt_col);                              // cpp:294-295, 338
-          fix_store_column<N, SPLITV>(el, G, x, g, true);
+          fix_store_column<N, SPLITV>(p, el, G, x, g, true);
         }
       }
       grid_sync<SPLITV>();
@@ -758,8 +761,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       hi = lo + width - 1 < kGrid ? lo + width - 1 : kGrid;
       if (lg < 4) {
         for (int g = lo; g <= hi; ++g) {
-          x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col, fast);   // cpp:294-295, 338
-          fix_store_column<N, SPLITV>(el, G, x, g, true);
+          x = rk4_dyn<FAST>(x, el.u, el.coef(), el.tau(p), el.inv(p), dt_col, fast);   // cpp:294-295, 338
+          fix_store_column<N, SPLITV>(p, el, G, x, g, true);
         }
       }
       grid_sync<SPLITV>();
@@ -785,13 +788,13 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   if (lg < 2 * E) {
     const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
-    gst<COH>(&p.state[(long long)(row + ax) * B + a], G.pos(kGrid, e, ax));
-    gst<COH>(&p.state[(long long)(row + 2 + ax) * B + a], G.vel(kGrid, e, ax));
+    gst_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state, G.pos(kGrid, e, ax));
+    gst_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state, G.vel(kGrid, e, ax));
   }
   if (lg == 0) {
     if (NOISE) p.consumed[a] = cur;
-    gst<COH>(&p.tcur[a], t0 + dt);
-    if (scored) { gst<COH>(&p.state[0 * B + a], TAS); gst<COH>(&p.state[1 * B + a], TBS); }
+    gst_at<COH>(p.tcur, a, p.n_tcur, t0 + dt);
+    if (scored) { gst_at<COH>(p.state, 0 * B + a, p.n_state, TAS); gst_at<COH>(p.state, 1 * B + a, p.n_state, TBS); }
     if (had_events) {
       atomicAdd(&p.counters[CNT_EVENT_STEPS], 1ull);
       if (n_resolved) atomicAdd(&p.counters[CNT_RESOLVED], (unsigned long long)n_resolved);

@@ -2,16 +2,19 @@
 // gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rgs_hip.h"
 #include "gsim_kernels.hpp"
+#include "auto_rates.h"
 
 using namespace gsim;
 
@@ -109,13 +112,7 @@ struct rgs_sim {
   double *vgrid = nullptr;         // split-grid velocity rows (two-lane hybrid, n >= 4)
   size_t vgrid_cap = 0;
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
-  // pooled kernel: chip-wide task queue (gsim_kernels.hpp, k_step_pool)
-  unsigned long long *q_ctrl = nullptr, *q_task = nullptr;
-  unsigned *q_seq = nullptr;
-  int *q_pending = nullptr;
-  unsigned long long q_slots = 0;  // ring size, a power of two >= B
-  unsigned long long pool_launches = 0;
-  int n_simds = 1024;              // CUs x 4 (hipDeviceProp_t::multiProcessorCount)
+  int n_cus = 256;                 // hipDeviceProp_t::multiProcessorCount
 };
 
 namespace {
@@ -276,6 +273,17 @@ int launch_kind(rgs_sim *s, const StepArgs &a, int kind, int mode) {
 
 constexpr long long kNoiseMaxArenas = 4096;     // tapes are host-generated and uploaded every step
 
+// fn(lo, hi) over [0, n) on up to 16 host threads (the per-arena generators are independent).
+template <typename F>
+void parallel_arenas(long long n, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const long long nt = std::max<long long>(1, std::min<long long>(std::min<long long>(16, hw ? hw : 1), n / 64));
+  if (nt <= 1) { fn(0, n); return; }
+  std::vector<std::thread> pool;
+  for (long long t = 0; t < nt; ++t) pool.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt); });
+  for (auto &th : pool) th.join();
+}
+
 // One step with w_stdev_ != 0.  The host draws a tape of N(0,1) values per arena from COPIES of the
 // arena's generator, the wave kernel consumes them in the reference's call order and reports how many
 // it used, and the real generators are then advanced by exactly that many draws.  A step whose events
@@ -301,12 +309,14 @@ int noise_step(rgs_sim *s, StepArgs a) {
       s->tape_cap = need;
     }
     s->tape_host.resize(need);
-    for (long long ar = 0; ar < B; ++ar) {
-      std::default_random_engine e = s->reng[ar];              // copies: the originals advance later
-      std::normal_distribution<double> d = s->wdist[ar];
-      double *t = s->tape_host.data() + (size_t)ar * T;
-      for (int k = 0; k < T; ++k) t[k] = d(e);                 // w_dist_(reng_), src/GameSim.cpp:66-67
-    }
+    parallel_arenas(B, [&](long long lo, long long hi) {
+      for (long long ar = lo; ar < hi; ++ar) {
+        std::default_random_engine e = s->reng[ar];            // copies: the originals advance later
+        std::normal_distribution<double> d = s->wdist[ar];
+        double *t = s->tape_host.data() + (size_t)ar * T;
+        for (int k = 0; k < T; ++k) t[k] = d(e);               // w_dist_(reng_), src/GameSim.cpp:66-67
+      }
+    });
     HIP_TRY(hipMemcpyAsync(s->tape_dev, s->tape_host.data(), sizeof(double) * need, hipMemcpyHostToDevice, s->stream));
     a.tape = s->tape_dev; a.tape_len = T; a.sigma = s->sigma; a.consumed = s->consumed_dev;
     a.n_steps = 1; a.ctl_stride = 0;
@@ -319,8 +329,10 @@ int noise_step(rgs_sim *s, StepArgs a) {
     bool overflow = false;
     for (long long ar = 0; ar < B; ++ar) overflow |= s->consumed_host[ar] > T;
     if (!overflow) {
-      for (long long ar = 0; ar < B; ++ar)
-        for (int k = 0; k < s->consumed_host[ar]; ++k) (void)s->wdist[ar](s->reng[ar]);
+      parallel_arenas(B, [&](long long lo, long long hi) {
+        for (long long ar = lo; ar < hi; ++ar)
+          for (int k = 0; k < s->consumed_host[ar]; ++k) (void)s->wdist[ar](s->reng[ar]);
+      });
       return RGS_OK;
     }
     if (attempt == 1) return fail(RGS_ERR_HIP, "noise_step: worst-case tape still too short (internal error)");
@@ -369,6 +381,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.wall_ends = ok ? 1 : 0;
   }
   a.counters = s->counters;
+  a.n_state = (long long)s->S * s->B; a.n_tcur = s->B; a.n_damage = (long long)s->P * s->P * s->B;
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr; a.vgrid = nullptr;
@@ -406,29 +419,36 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     s->window_steps = 0;
   }
   if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
-  // Which kernel: estimated arena-steps/s (x1e6) from rates measured on MI355X (profiles/r01).  The
-  // one-lane hybrid needs 65 536 arenas to put a wave on every SIMD, the two-lane hybrid 32 768; the
-  // wave-per-arena kernel spreads even a few hundred arenas over the whole chip (one wave each) and is
-  // 2-4x faster than either hybrid below ~8k arenas (1024 x 2v2: 5.2e7 vs 2.4e7), modelled as
-  // B / (t0 + B / saturated rate).  Examples: 65 536 x 4v4 one-lane 5.0e8 (two-lane 4.9e8); C5,
-  // 32 768 x 4v4, two-lane 2.8e8 (one-lane 1.5e8); the drop-in GameSim (1 arena) uses the wave kernel.
-  // hybrids: measured at 32 768 and 65 536 arenas (tools/sweep.sh, profiles/r01/sweep_team_size.json), linear in
-  // between and below, flat above
-  static const double one32[8] = {0, 622, 595, 368, 241, 163, 98, 68}, one65[8] = {0, 1442, 1072, 721, 503, 314, 188, 131};
-  static const double two32[8] = {0, 681, 780, 503, 439, 293, 235, 189}, two65[8] = {0, 1387, 810, 593, 488, 324, 247, 197};
-  static const double wave_sat[8] = {0, 320, 280, 230, 186, 130, 90, 62};
-  static const double wave_t0_us[8] = {0, 13, 13, 13, 12, 12, 11, 10};
+  // Which kernel: estimated arena-steps/s (x1e6) from the rates in auto_rates.h, a header GENERATED from a sweep on
+  // MI355X (tools/sweep.py -> profiles/r02/sweep_auto.json -> tools/rates_to_header.py); nothing measured is typed in
+  // here.  The hybrids are measured at 32 768 and 65 536 arenas (linear in between and below, flat above: the one-lane
+  // kernels need 65 536 arenas to put a wavefront on every SIMD, the two-lane one 32 768); the wave-per-arena kernel
+  // spreads even a few hundred arenas over the whole chip and is modelled as B / (t0 + B / saturated rate) through its
+  // 1 024- and 65 536-arena points.  Launches of few steps are tail-dominated and have their own table ("short").
+  // The pooled hybrid needs its 256-arena workgroups (141 KB of LDS) resident all at once: one per CU at most.
+  const int regime = n_steps <= 64 ? 0 : 1;
   const double Bd = (double)s->B;
-  auto hybrid_rate = [Bd](double r32, double r65) {
+  auto hybrid_rate = [&](int kern) {
+    const double r32 = kAutoRate[regime][kern][0][s->n], r65 = kAutoRate[regime][kern][1][s->n];
     if (Bd <= 32768.0) return r32 * Bd / 32768.0;
     if (Bd >= 65536.0) return r65;
     return r32 + (r65 - r32) * (Bd - 32768.0) / 32768.0;
   };
-  const double est_one = hybrid_rate(one32[s->n], one65[s->n]);
-  const double est_two = hybrid_rate(two32[s->n], two65[s->n]);
-  const double est_wave = Bd / (wave_t0_us[s->n] + Bd / wave_sat[s->n]);
-  int best = est_two > est_one ? RGS_VARIANT_HYBRID2 : RGS_VARIANT_HYBRID;
-  if (est_wave > (est_two > est_one ? est_two : est_one)) best = RGS_VARIANT_WAVE;
+  const double est_one = hybrid_rate(1), est_two = hybrid_rate(2);
+  const double est_pool = (s->B + 255) / 256 <= (long long)s->n_cus ? hybrid_rate(3) : 0.0;
+  double est_wave = 0.0;
+  {
+    const double sat = kAutoRate[regime][0][1][s->n], r1k = kAutoWave1k[regime][s->n];
+    if (sat > 0.0 && r1k > 0.0) {
+      const double t0 = 1024.0 / r1k - 1024.0 / sat;           // microseconds
+      est_wave = Bd / ((t0 > 0.0 ? t0 : 0.0) + Bd / sat);
+    }
+  }
+  int best = RGS_VARIANT_HYBRID;
+  double best_rate = est_one;
+  if (est_two > best_rate) { best = RGS_VARIANT_HYBRID2; best_rate = est_two; }
+  if (est_pool > best_rate) { best = RGS_VARIANT_POOL; best_rate = est_pool; }
+  if (est_wave > best_rate) { best = RGS_VARIANT_WAVE; best_rate = est_wave; }
   const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : best);
   const bool fast = use_fast_division(s);
   // The power-of-two modes fold 1/tau_player into the lane pass' step constants (gsim_lane.hpp): those
@@ -449,14 +469,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.vgrid = s->vgrid;
     return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
   }
-  if (variant == RGS_VARIANT_POOL && n_steps <= 65535 && s->B < (1ll << 26)) {
-    a.q_ctrl = s->q_ctrl; a.q_task = s->q_task; a.q_seq = s->q_seq; a.q_pending = s->q_pending;
-    a.q_mask = s->q_slots - 1;
-    s->pool_launches++;
-    a.q_done_target = s->pool_launches * (unsigned long long)((s->B + 63) / 64);
-    a.q_stay = ((s->B + 63) / 64) <= (long long)s->n_simds ? 1 : 0;
-    return launch_kind(s, a, LAUNCH_POOL, div_mode);
-  }
+  if (variant == RGS_VARIANT_POOL && n_steps < (1 << 26)) return launch_kind(s, a, LAUNCH_POOL, div_mode);
   if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
   return launch_kind(s, a, LAUNCH_WAVE, !fast ? 0 : (s->one_step_ok ? 3 : 1));
 
@@ -470,16 +483,6 @@ int do_reset(rgs_sim *s, const double *x0_host, int batched) {
   hipError_t e = hipMemcpyAsync(x0_dev, x0_host, n * sizeof(double), hipMemcpyHostToDevice, s->stream);
   if (e == hipSuccess) e = gsim_ops(s->n)->reset(s->state, s->tcur, s->damage, x0_dev, batched, s->B, s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(s->counters, 0, (CNT_N + STAMP_N) * sizeof(unsigned long long), s->stream);
-#ifndef GSIM_NOQ
-  if (e == hipSuccess) e = hipMemsetAsync(s->q_ctrl, 0, sizeof(unsigned long long) * 8, s->stream);
-#endif
-#ifndef GSIM_NOQ
-  if (e == hipSuccess) e = hipMemsetAsync(s->q_seq, 0, sizeof(unsigned) * s->q_slots, s->stream);
-#endif
-#ifndef GSIM_NOQ
-  if (e == hipSuccess) e = hipMemsetAsync(s->q_pending, 0, sizeof(int) * (size_t)((s->B + 63) / 64), s->stream);
-#endif
-  s->pool_launches = 0;
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   hipFree(x0_dev);
   if (e != hipSuccess) return fail(RGS_ERR_HIP, std::string("reset: ") + hipGetErrorString(e));
@@ -505,7 +508,7 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(RGS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
   rgs_sim *s = new rgs_sim();
-  s->n_simds = 4 * prop.multiProcessorCount;
+  s->n_cus = prop.multiProcessorCount;
   s->B = n_arenas;
   s->n = n_per_team;
   s->P = 2 * n_per_team;
@@ -522,12 +525,6 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   if (e == hipSuccess) e = dev_alloc(s, &s->ctl, sizeof(double) * s->P * 2 * s->B, "ctl");
   if (e == hipSuccess) e = dev_alloc(s, &s->counters, sizeof(unsigned long long) * (CNT_N + STAMP_N), "counters");
   if (e == hipSuccess) e = dev_alloc(s, &s->flags, (size_t)s->B, "flags");
-  s->q_slots = 64;
-  while (s->q_slots < (unsigned long long)s->B) s->q_slots <<= 1;
-  if (e == hipSuccess) e = dev_alloc(s, &s->q_ctrl, sizeof(unsigned long long) * 8, "q_ctrl");
-  if (e == hipSuccess) e = dev_alloc(s, &s->q_task, sizeof(unsigned long long) * s->q_slots, "q_task");
-  if (e == hipSuccess) e = dev_alloc(s, &s->q_seq, sizeof(unsigned) * s->q_slots, "q_seq");
-  if (e == hipSuccess) e = dev_alloc(s, &s->q_pending, sizeof(int) * (size_t)((s->B + 63) / 64), "q_pending");
   if (e != hipSuccess) {
     std::string m = std::string("rgs_create: ") + hipGetErrorString(e);
     rgs_destroy(s);
@@ -546,7 +543,6 @@ int rgs_destroy(rgs_sim *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
-  dev_free(s, s->q_ctrl); dev_free(s, s->q_task); dev_free(s, s->q_seq); dev_free(s, s->q_pending);
   dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -679,6 +675,14 @@ int rgs_set_state(rgs_sim *s, const double *state_host, const double *time_host)
   HIP_TRY(hipMemcpyAsync(s->state, state_host, sizeof(double) * s->S * s->B, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->tcur, time_host, sizeof(double) * s->B, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemsetAsync(s->damage, 0, sizeof(double) * s->P * s->P * s->B, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_set_damage(rgs_sim *s, const double *damage_host) {
+  if (!s || !damage_host) return fail(RGS_ERR_ARG, "rgs_set_damage: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(s->damage, damage_host, sizeof(double) * s->P * s->P * s->B, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RGS_OK;
 }
@@ -841,7 +845,7 @@ int rgs_set_sparse_watch(rgs_sim *s, int enable) {
   if (enable != 0 && enable != 1 && enable != 2 && enable != 5 && enable != 10)
     return fail(RGS_ERR_ARG, "rgs_set_sparse_watch: interval must be 0 (off), 1 (default interval), 2, 5 or 10");
   s->sparse_watch = enable != 0;
-  if (enable >= 2) s->watch_every = enable;
+  s->watch_every = enable >= 2 ? enable : 0;                  // 1 = back to the default interval
   return RGS_OK;
 }
 

@@ -79,23 +79,51 @@ def log_record(t, state, damage):
 
 
 class SimStateView:
-    """Index helper over a state vector, N-generic counterpart of py/src/SimState.py:6-12."""
+    """N-generic counterpart of py/src/SimState.py:4-43: index constants over one arena's state vector plus
+    the reference's accessors (get_player_pos / vel / state, get_puck_pos / vel / state, transpose), each
+    returning a copy like the reference's deepcopy.  At n = 2 the constants are the reference's
+    (TAS 0, TBS 1, PK 2, A1 6, A2 10, B1 14, B2 18); for other team sizes A<k> / B<k> exist for k = 1..n.
+    Policies written against the reference class (ClassicalTeam.run & co.) take this one unchanged.
+    """
 
-    def __init__(self, state, n_per_team=2):
-        self.state = np.array(state, dtype=np.float64, copy=True)
-        self.n = int(n_per_team)
+    def __init__(self, state, n_per_team=None):
+        self.state = np.array(state, dtype=np.float64, copy=True)         # copy.deepcopy(state), SimState.py:13
+        size = self.state.shape[0]
+        n = (size - 6) // 8 if n_per_team is None else int(n_per_team)
+        if size != 2 + 4 * (2 * n + 1):
+            raise TypeError("a %dv%d state has %d entries, got %d" % (n, n, 2 + 4 * (2 * n + 1), size))
+        self.n = n
         self.TAS, self.TBS, self.PK = 0, 1, 2
+        for k in range(1, n + 1):
+            setattr(self, "A%d" % k, self.offset("A", k))
+            setattr(self, "B%d" % k, self.offset("B", k))
 
     def offset(self, team, player_id):
-        k = {"A": 0, "B": self.n}[team] + (player_id - 1)
-        return 6 + 4 * k
+        if team not in ("A", "B") or not 1 <= int(player_id) <= self.n:
+            raise ValueError("team = 'A' or 'B', player_id = 1..%d (got %r, %r)" % (self.n, team, player_id))
+        return 6 + 4 * ({"A": 0, "B": self.n}[team] + int(player_id) - 1)
 
     def get_player_state(self, team, player_id):
         o = self.offset(team, player_id)
         return self.state[o:o + 4].copy()
 
+    def get_player_pos(self, team, player_id):
+        return self.get_player_state(team, player_id)[0:2]
+
+    def get_player_vel(self, team, player_id):
+        return self.get_player_state(team, player_id)[2:4]
+
     def get_puck_state(self):
         return self.state[2:6].copy()
+
+    def get_puck_pos(self):
+        return self.state[2:4].copy()
+
+    def get_puck_vel(self):
+        return self.state[4:6].copy()
+
+    def transpose(self):
+        return self.state.transpose().copy()
 
 
 class _DeviceBuffer:
@@ -297,13 +325,20 @@ class BatchedGameSim:
         _lib.check(self._L.rgs_get_time(self._h, _lib.dptr(out)))
         return out
 
-    def set_state(self, state, time=None):
+    def set_state(self, state, time=None, damage=None):
+        """Restore a checkpoint: state (S, B), time (B,) or scalar, damage (P, P, B) as returned by damage()
+        (zeroed when omitted).  Event counters and, with noise, the generators are not restored."""
         s = np.ascontiguousarray(state, dtype=np.float64)
         if s.shape != (self.state_size, self.n_arenas):
             raise TypeError("state must have shape (%d, %d)" % (self.state_size, self.n_arenas))
         t = np.zeros(self.n_arenas) if time is None else np.ascontiguousarray(
             np.broadcast_to(np.asarray(time, dtype=np.float64), (self.n_arenas,)))
         _lib.check(self._L.rgs_set_state(self._h, _lib.dptr(s), _lib.dptr(t)))
+        if damage is not None:
+            d = np.ascontiguousarray(damage, dtype=np.float64)
+            if d.size != self.players * self.players * self.n_arenas:
+                raise TypeError("damage must have %d x %d x %d entries" % (self.players, self.players, self.n_arenas))
+            _lib.check(self._L.rgs_set_damage(self._h, _lib.dptr(d)))
 
     def counters(self):
         out = (C.c_int64 * 8)()

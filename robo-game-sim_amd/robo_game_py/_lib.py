@@ -42,6 +42,7 @@ SIGNATURES = {
     "rgs_get_damage": (C.c_int, [_vp, _dp]),
     "rgs_get_time": (C.c_int, [_vp, _dp]),
     "rgs_set_state": (C.c_int, [_vp, _dp, _dp]),
+    "rgs_set_damage": (C.c_int, [_vp, _dp]),
     "rgs_state_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "rgs_copy_state_to_device": (C.c_int, [_vp, _vp]),
     "rgs_stream": (C.c_int, [_vp, C.POINTER(_vp)]),

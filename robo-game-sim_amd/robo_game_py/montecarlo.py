@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-from . import BatchedGameSim, GameSim, log_record
+from . import BatchedGameSim, GameSim, SimStateView, log_record
 
 
 def write_configuration(mc_params):
@@ -42,34 +42,7 @@ def steps_per_run(mc_params):
     return int(math.ceil(mc_params.T / mc_params.dt))
 
 
-class _StateView:
-    """Minimal py/src/SimState.py stand-in (index constants + state copy) for policies written for it."""
-    TAS, TBS, PK, A1, A2, B1, B2 = 0, 1, 2, 6, 10, 14, 18
-
-    def __init__(self, state):
-        self.state = np.array(state, dtype=np.float64, copy=True)
-
-    def get_player_state(self, team, player_id):
-        o = {("A", 1): 6, ("A", 2): 10, ("B", 1): 14, ("B", 2): 18}[(team, player_id)]
-        return self.state[o:o + 4]
-
-    def get_player_pos(self, team, player_id):
-        return self.get_player_state(team, player_id)[0:2].copy()
-
-    def get_player_vel(self, team, player_id):
-        return self.get_player_state(team, player_id)[2:4].copy()
-
-    def get_puck_state(self):
-        return self.state[2:6].copy()
-
-    def get_puck_pos(self):
-        return self.state[2:4].copy()
-
-    def get_puck_vel(self):
-        return self.state[4:6].copy()
-
-    def transpose(self):
-        return self.state.transpose().copy()
+_StateView = SimStateView        # the public, N-generic look-alike of py/src/SimState.py
 
 
 def monte_carlo(mc_params, team_A_run_method, team_B_run_method, cbf_run_method=None, state_class=None,
@@ -112,26 +85,48 @@ def mindless_policy(state, k, t, seeds):
     return u
 
 
+NOISE_MAX_ARENAS = 4096      # include/rgs_hip.h: noise != 0 needs host-generated draw tapes, <= 4096 arenas per handle
+
+
 def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=0, write_logs=True, logged_runs=None,
-                        sim=None):
+                        sim=None, _first_run=1, _write_config=True):
     """All runs of the ensemble at once.
 
     policy(state (S, B), k, t, seeds (B,)) -> controls (P, 2, B); called once per step for the whole batch
     (k = step index, t = k*dt accumulated like py/run_sim.py:75).  logged_runs: iterable of 1-based run
     numbers whose mc_run_<i>.log to write (default: all when write_logs).
+    With noise_stdev != 0 an ensemble of more than 4096 runs is stepped in chunks of 4096 (one handle each,
+    the stepper's limit for host-generated noise tapes); run i keeps seed i either way.
     Returns dict(state (S, B), scores (2, B), damage (P, P, B), undecided (B,), steps).
     """
     B = int(mc_params.num_runs)
+    if float(mc_params.noise_stdev) != 0.0 and B > NOISE_MAX_ARENAS and sim is None:
+        import copy
+        if _write_config:
+            write_configuration(mc_params)
+        parts = []
+        for lo in range(0, B, NOISE_MAX_ARENAS):
+            sub = copy.copy(mc_params)
+            sub.num_runs = min(NOISE_MAX_ARENAS, B - lo)
+            parts.append(monte_carlo_batched(sub, policy, n_per_team, device, write_logs, logged_runs, None,
+                                             _first_run=_first_run + lo, _write_config=False))
+        return dict(state=np.concatenate([q["state"] for q in parts], axis=1),
+                    scores=np.concatenate([q["scores"] for q in parts], axis=1),
+                    damage=np.concatenate([q["damage"] for q in parts], axis=2),
+                    undecided=np.concatenate([q["undecided"] for q in parts]), steps=parts[0]["steps"])
     own = sim is None
     sim = sim or BatchedGameSim(B, n_per_team, device)
     P = sim.players
-    seeds = np.arange(1, B + 1)                                             # py/MonteCarlo.py:23,29
-    write_configuration(mc_params)
-    # run i of the reference uses seed = i (py/MonteCarlo.py:29); arena a draws from seed + a, so seed = 1
+    seeds = np.arange(_first_run, _first_run + B)                          # py/MonteCarlo.py:23,29
+    if _write_config:
+        write_configuration(mc_params)
+    # run i of the reference uses seed = i (py/MonteCarlo.py:29); arena a draws from seed + a, so seed = first run
     sim.reset(mc_params.dt, mc_params.winning_score, np.asarray(mc_params.x0_ball, dtype=np.float64),
-              float(mc_params.noise_stdev), False, "", 1, mc_params.tau_puck, mc_params.tau_player, mc_params.player_mass, mc_params.puck_mass)
+              float(mc_params.noise_stdev), False, "", int(_first_run), mc_params.tau_puck, mc_params.tau_player,
+              mc_params.player_mass, mc_params.puck_mass)
     N = steps_per_run(mc_params)
-    runs = list(range(1, B + 1)) if logged_runs is None else [int(r) for r in logged_runs]
+    mine = range(_first_run, _first_run + B)
+    runs = list(mine) if logged_runs is None else [int(r) for r in logged_runs if int(r) in mine]
     files = {}
     if write_logs:
         for r in runs:
@@ -142,8 +137,8 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
         if files:
             rec = sim.run_table_recorded(controls[None])[0]                 # (R, B)
             for r, f in files.items():
-                if rec[R - 1, r - 1] != 0.0:                                # a decided game logs nothing
-                    f.write(rec[:R - 1, r - 1].tobytes())
+                if rec[R - 1, r - _first_run] != 0.0:                       # a decided game logs nothing
+                    f.write(rec[:R - 1, r - _first_run].tobytes())
             return None
         sim.step(controls)
         return None

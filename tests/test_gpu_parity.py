@@ -342,12 +342,14 @@ def test_set_state_and_ragged_batch(rgp, oracle):
     a = rgp.BatchedGameSim(B, n)
     a.reset(0.05, 1000, x0)
     mid = a.run_table(table[:60])
-    tmid = a.time()
+    tmid, dmid = a.time(), a.damage()
     full = a.run_table(table[60:])
     b = rgp.BatchedGameSim(B, n)
     b.reset(0.05, 1000, x0)
-    b.set_state(mid, tmid)
+    b.set_state(mid, tmid, dmid)                               # checkpoint = state + time + damage
     assert_same(b.run_table(table[60:]), full, "restart")
+    assert_same(b.damage(), a.damage(), "restart damage")
+    assert a.damage().sum() > dmid.sum() > 0.0
     a.close()
     b.close()
 

@@ -124,3 +124,24 @@ def test_mc_inputs_are_a_function_of_the_run_seed_only():
     a2, p2 = w.mc_inputs(np.arange(5, 9), 2)
     assert np.array_equal(a1[:, 4:], a2) and np.array_equal(p1[:, 4:], p2)      # sharding the runs changes nothing
     assert a1.shape == (4, 8) and np.all((a1 >= 0.5) & (a1 < 4.0)) and np.all((p1 >= 0) & (p1 < 2 * np.pi))
+
+
+def test_sim_state_view_has_the_reference_accessors(rgp):
+    """py/src/SimState.py:4-43: constants and accessors, copies not views; N-generic."""
+    st = np.arange(22, dtype=np.float64)
+    v = rgp.SimStateView(st)
+    assert (v.TAS, v.TBS, v.PK, v.A1, v.A2, v.B1, v.B2) == (0, 1, 2, 6, 10, 14, 18)
+    assert np.array_equal(v.get_player_state("B", 1), [14, 15, 16, 17])
+    assert np.array_equal(v.get_player_pos("A", 2), [10, 11]) and np.array_equal(v.get_player_vel("A", 2), [12, 13])
+    assert np.array_equal(v.get_puck_state(), [2, 3, 4, 5]) and np.array_equal(v.get_puck_pos(), [2, 3])
+    assert np.array_equal(v.get_puck_vel(), [4, 5]) and np.array_equal(v.transpose(), st)
+    p = v.get_player_pos("A", 1)
+    p[0] = -1.0
+    st[6] = -2.0
+    assert v.state[6] == 6.0                                   # deepcopy semantics in both directions
+    v7 = rgp.SimStateView(np.arange(62, dtype=np.float64))     # 7v7
+    assert v7.n == 7 and v7.A7 == 6 + 4 * 6 and v7.B1 == 6 + 4 * 7 and np.array_equal(v7.get_player_vel("B", 7), [60, 61])
+    with pytest.raises(ValueError):
+        v.get_player_state("A", 3)
+    with pytest.raises(TypeError):
+        rgp.SimStateView(np.zeros(23))
