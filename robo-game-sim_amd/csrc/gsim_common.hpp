@@ -31,6 +31,12 @@
 #ifndef GSIM_LANE_HINT
 #define GSIM_LANE_HINT 0
 #endif
+#ifndef GSIM_H2_SPLIT_BIG
+#define GSIM_H2_SPLIT_BIG 1        // two-lane hybrid, 6v6/7v7: velocity rows of the grid in global scratch
+#endif
+#ifndef GSIM_H2_SPLIT_4
+#define GSIM_H2_SPLIT_4 1          // the same at 4v4
+#endif
 #ifndef GSIM_STAMPS
 #define GSIM_STAMPS 0
 #endif

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
 // 5 % with it.
 template <int N>
 struct Hybrid2Split {
-  static constexpr bool value = N >= 6 || N == 4;
+  static constexpr bool value = (GSIM_H2_SPLIT_BIG && N >= 6) || (GSIM_H2_SPLIT_4 && N == 4);
   static constexpr int LDS_KB = GSIM_H2_LDS_KB;
 };
 

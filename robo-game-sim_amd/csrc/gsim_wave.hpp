@@ -334,21 +334,10 @@ struct EventSlots {
 template <int N>
 struct EventLane {
   int d, ax;
-  bool first, is_pair, my_axis, positive_wall, store, own_puck, with_puck, vertical;
-  double u;
-  // Everything else is a choice between a few per-batch constants (scalar registers): selected where it is used
-  // instead of being carried in vector registers through the event loop (the wave-per-arena kernel's budget).
-  __device__ __forceinline__ double coef() const { return own_puck ? 0.2 : 1.0; }
-  __device__ __forceinline__ double tau(const StepArgs &p) const { return own_puck ? p.tau_puck : p.tau_player; }
-  __device__ __forceinline__ double inv(const StepArgs &p) const { return own_puck ? p.inv_tau_puck : p.inv_tau_player; }
-  __device__ __forceinline__ double r_own() const { return own_puck ? kRPuck : kRPlayer; }
-  __device__ __forceinline__ double rsum() const { return with_puck ? kRPlayer + kRPuck : kRPlayer + kRPlayer; }   // ri + rj
-  __device__ __forceinline__ double lt(const StepArgs &p) const { return with_puck ? p.lt_pk : p.lt_pp; }   // s <= lt  <=>  rsum - sqrt(s) > 0
-  __device__ __forceinline__ double wall() const { return vertical ? kY / 2.0 : kX / 2.0; }
-  // ((1.01*r_own)/(ri+rj)), ((1.1*r_own)/(ri+rj)): cpp:263-264, 588-589; (2*m_other)/(mi+mj): cpp:273-274 (host-computed quotients)
-  __device__ __forceinline__ double push101(const StepArgs &p) const { return !with_puck ? p.push101_pp : (own_puck ? p.push101_pkk : p.push101_plk); }
-  __device__ __forceinline__ double push11(const StepArgs &p) const { return !with_puck ? p.push11_pp : (own_puck ? p.push11_pkk : p.push11_plk); }
-  __device__ __forceinline__ double mass_ratio(const StepArgs &p) const { return !with_puck ? p.ratio_pp : (own_puck ? p.ratio_vs_player : p.ratio_vs_puck); }
+  bool first, is_pair, my_axis, positive_wall, store;
+  double u, coef, tau, inv, r_own, rsum, lt, wall;
+  double push101, push11;    // ((1.01*r_own)/(ri+rj)), ((1.1*r_own)/(ri+rj)): cpp:263-264, 588-589 (host-computed quotients)
+  double mass_ratio;         // (2*m_other)/(mi+mj), cpp:273-274
 };
 
 template <int N, bool SPLITV>
@@ -361,12 +350,20 @@ __device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const Grid
   c.ax = lg & 1;
   c.d = (c.is_pair && !c.first) ? cj : ci;
   c.store = c.is_pair || c.first;
-  c.own_puck = c.d == PK;
-  c.with_puck = ci == PK || cj == PK;
+  c.r_own = disc_radius<N>(c.d);
   c.u = G.ctl(c.d, c.ax);
-  c.vertical = kind == UP || kind == DOWN;
-  c.my_axis = c.vertical ? (c.ax == 1) : (c.ax == 0);
+  c.coef = c.d == PK ? 0.2 : 1.0;
+  c.tau = c.d == PK ? p.tau_puck : p.tau_player;
+  c.inv = c.d == PK ? p.inv_tau_puck : p.inv_tau_player;
+  const bool with_puck = ci == PK || cj == PK;
+  c.rsum = disc_radius<N>(ci) + disc_radius<N>(c.is_pair ? cj : ci);
+  c.lt = with_puck ? p.lt_pk : p.lt_pp;                      // s <= lt  <=>  rsum - sqrt(s) > 0
+  c.push101 = !with_puck ? p.push101_pp : (c.d == PK ? p.push101_pkk : p.push101_plk);
+  c.push11 = !with_puck ? p.push11_pp : (c.d == PK ? p.push11_pkk : p.push11_plk);
+  c.mass_ratio = !with_puck ? p.ratio_pp : (c.d == PK ? p.ratio_vs_player : p.ratio_vs_puck);
+  c.my_axis = (kind == UP || kind == DOWN) ? (c.ax == 1) : (c.ax == 0);
   c.positive_wall = (kind == UP || kind == RIGHT);
+  c.wall = (kind == UP || kind == DOWN) ? kY / 2.0 : kX / 2.0;
   return c;
 }
 
@@ -374,19 +371,19 @@ __device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const Grid
 // into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).  Select-based: the
 // square root is taken whether or not the discs overlap.
 template <int N, bool SPLITV>
-__device__ __forceinline__ void fix_store_column(const StepArgs &p, const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
+__device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
                                                  bool wall_fix) {
   if (c.is_pair) {
     const double po = quad_xor2(x.p);
     const double pij = c.first ? po - x.p : x.p - po;
     const double sq = pij * pij;
     const double s = sq + quad_xor1(sq);
-    const double overlap = c.rsum() - sqrt_ieee(s);
-    const double cc = (c.first ? -c.push11(p) : c.push11(p)) * overlap;    // -(a*b) == (-a)*b exactly
+    const double overlap = c.rsum - sqrt_ieee(s);
+    const double cc = (c.first ? -c.push11 : c.push11) * overlap;    // -(a*b) == (-a)*b exactly
     const double moved = x.p + cc * pij;                             // x - c*pij == x + (-(c*pij))
-    x.p = (s <= c.lt(p)) ? moved : x.p;
+    x.p = (s <= c.lt) ? moved : x.p;
   } else if (c.my_axis && wall_fix) {
-    const double overlap = c.positive_wall ? (x.p + c.r_own() - c.wall()) : (-x.p + c.r_own() - c.wall());
+    const double overlap = c.positive_wall ? (x.p + c.r_own - c.wall) : (-x.p + c.r_own - c.wall);
     const double cc = 1.1 * overlap;
     const double moved = c.positive_wall ? x.p - cc : x.p + cc;
     x.p = (overlap > 0) ? moved : x.p;
@@ -409,8 +406,8 @@ __device__ __forceinline__ void finish_columns(const StepArgs &p, const GridView
     x.v = G.vel(from - 1, c.d, c.ax);
     const bool fast = FAST != 0 && fast_division_safe(c.u, x.v);
     for (int g = from; g <= to; ++g) {
-      x = rk4_dyn<FAST>(x, c.u, c.coef(), c.tau(p), c.inv(p), dt_col, fast);
-      fix_store_column<N, SPLITV>(p, c, G, x, g, true);
+      x = rk4_dyn<FAST>(x, c.u, c.coef, c.tau, c.inv, dt_col, fast);
+      fix_store_column<N, SPLITV>(c, G, x, g, true);
     }
   }
   grid_sync<SPLITV>();
@@ -669,14 +666,14 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     auto noisy = [&](Chain xx, double hh) {
       const int c0 = cur + 8 * (call * np + slot);
       ++call;
-      return rk4_axis_noise(xx, el.u, el.coef(), el.tau(p), hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax);
+      return rk4_axis_noise(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax);
     };
     if (lg < 4) {
       x.p = G.pos(base - 1, el.d, el.ax);
       x.v = G.vel(base - 1, el.d, el.ax);
       fast = FAST != 0 && fast_division_safe(el.u, x.v);
       if (NOISE) x = noisy(x, dt_t); else
-      x = rk4_dyn<FAST>(x, el.u, el.coef(), el.tau(p), el.inv(p), dt_t, fast);   // cpp:255-256, 309
+      x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_t, fast);   // cpp:255-256, 309
 
       if (is_pair) {                                         // cpp:242-282
         {                                                    // cpp:259-265 (pij not normalised)
@@ -684,10 +681,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           const double pij = el.first ? po - x.p : x.p - po;
           const double sq = pij * pij;
           const double s = sq + quad_xor1(sq);
-          const double overlap = el.rsum() - sqrt_ieee(s);
-          const double c = (el.first ? -el.push101(p) : el.push101(p)) * overlap;   // ((1.01*r)/(ri+rj))*overlap, sign of the push
+          const double overlap = el.rsum - sqrt_ieee(s);
+          const double c = (el.first ? -el.push101 : el.push101) * overlap;   // ((1.01*r)/(ri+rj))*overlap, sign of the push
           const double moved = x.p + c * pij;                // x - c*pij == x + (-c)*pij exactly
-          x.p = (s <= el.lt(p)) ? moved : x.p;                  // only if overlap > 0
+          x.p = (s <= el.lt) ? moved : x.p;                  // only if overlap > 0
         }
         {                                                    // elastic impulse, cpp:268-274
           const double po = quad_xor2(x.p), vo = quad_xor2(x.v);
@@ -695,7 +692,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
           const double pr = dv * dp, sq = dp * dp;
           const double dot1 = pr + quad_xor1(pr);
           const double dot2 = sq + quad_xor1(sq);
-          const double s = div_ieee(el.mass_ratio(p) * dot1, dot2);   // ((2*m_other)/(mi+mj))*dot1/dot2
+          const double s = div_ieee(el.mass_ratio * dot1, dot2);   // ((2*m_other)/(mi+mj))*dot1/dot2
           if (ci != PK && cj != PK) {                        // damage, cpp:277-282
             const double dvsq = dv * dv;
             const double dv_sq = 0.01 * (dvsq + quad_xor1(dvsq));
@@ -720,9 +717,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       } else if (NOISE) {
         x = noisy(x, dt_col - dt_t);
       } else {
-        x = rk4_dyn<FAST>(x, el.u, el.coef(), el.tau(p), el.inv(p), dt_col - dt_t, fast);   // cpp:287-288, 331
+        x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col - dt_t, fast);   // cpp:287-288, 331
       }
-      fix_store_column<N, SPLITV>(p, el, G, x, base, !goal);    // cpp:289, 332 (no wall push after a goal, cpp:324-327)
+      fix_store_column<N, SPLITV>(el, G, x, base, !goal);    // cpp:289, 332 (no wall push after a goal, cpp:324-327)
     }
     goal = __shfl(goal ? 1 : 0, gbase) != 0;
     if (goal) {                                              // cpp:324-326
@@ -743,7 +740,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       if (lg < 4) {
         for (int g = base + 1; g <= kGrid; ++g) {
           x = noisy(x, dt_col);                              // cpp:294-295, 338
-          fix_store_column<N, SPLITV>(p, el, G, x, g, true);
+          fix_store_column<N, SPLITV>(el, G, x, g, true);
         }
       }
       grid_sync<SPLITV>();
@@ -761,8 +758,8 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
       hi = lo + width - 1 < kGrid ? lo + width - 1 : kGrid;
       if (lg < 4) {
         for (int g = lo; g <= hi; ++g) {
-          x = rk4_dyn<FAST>(x, el.u, el.coef(), el.tau(p), el.inv(p), dt_col, fast);   // cpp:294-295, 338
-          fix_store_column<N, SPLITV>(p, el, G, x, g, true);
+          x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col, fast);   // cpp:294-295, 338
+          fix_store_column<N, SPLITV>(el, G, x, g, true);
         }
       }
       grid_sync<SPLITV>();
