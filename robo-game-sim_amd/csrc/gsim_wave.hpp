@@ -569,8 +569,9 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
   // discs stay in contact the re-scan finds the next event in column base itself, and that event
   // re-integrates the same discs from there again: the 49 events of a step that runs into the iteration
   // cap (a puck spawned inside a player, C2: 4.5 % of the arenas in their first step) recompute ~2400
-  // columns of which ~100 are ever read.  Here the columns are produced in growing chunks (1, 3, then
-  // half a group's width), each chunk scanned as soon as it exists -- lanes of the lower half of the
+  // columns of which ~100 are ever read.  Here, once contact is being sustained (an event on the discs of
+  // the event before it; an isolated event produces all its columns at once), the columns are produced in
+  // growing chunks (1, 3, then half a group's width), each chunk scanned as soon as it exists -- lanes of the lower half of the
   // group take disc i's columns, the upper half disc j's; the two scans are independent of each other
   // since neither writes the grid -- and production stops once both discs have their event.  What is
   // left (columns vu+1..50 of the "pending" discs, to be continued from grid column vu under the
@@ -598,8 +599,10 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     counter++;
     if ((ci == PK || cj == PK) && scored) { n_skipped++; continue; }   // cpp:230-231
     const bool is_pair = ckind == PAIR;
-    bool repeats = !NOISE && last_i >= 0 && ct == last_t && ckind == last_kind &&
-                   ((ci == last_i && cj == last_j) || (ci == last_j && cj == last_i));
+    // the same discs as the event carried out just before: contact is being sustained, produce columns lazily
+    const bool same_discs = last_i >= 0 && is_pair == (last_kind == PAIR) &&
+                            ((ci == last_i && cj == last_j) || (ci == last_j && cj == last_i));
+    bool repeats = !NOISE && same_discs && ct == last_t && ckind == last_kind;
     if (repeats && is_pair) {                                // the partner's own event, if it has one (slot cj)
       double tb; int mb;
       ev.get(cj, tb, mb);
@@ -720,6 +723,12 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
         x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col - dt_t, fast);   // cpp:287-288, 331
       }
       fix_store_column<N, SPLITV>(el, G, x, base, !goal);    // cpp:289, 332 (no wall push after a goal, cpp:324-327)
+      if (!NOISE && !same_discs) {                           // an isolated event: all remaining columns at once (one sync, full-width scans)
+        for (int g = base + 1; g <= kGrid; ++g) {
+          x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col, fast);   // cpp:294-295, 338
+          fix_store_column<N, SPLITV>(el, G, x, g, true);
+        }
+      }
     }
     goal = __shfl(goal ? 1 : 0, gbase) != 0;
     if (goal) {                                              // cpp:324-326
@@ -735,7 +744,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     double ti = 0.0, tj = 0.0;
     int ji = -1, ki = -1, jj = -1, kj = -1;
     constexpr int H2 = GW / 2;
-    int lo = base, hi = NOISE ? kGrid : base;
+    int lo = base, hi = (NOISE || !same_discs) ? kGrid : base;
     if (NOISE && base < kGrid) {                             // noise: the whole remainder in the reference's call order
       if (lg < 4) {
         for (int g = base + 1; g <= kGrid; ++g) {
