@@ -1,5 +1,5 @@
-# Round gate on the GPU box: GPU tests, smoke, every bench config (C2 with ALL arenas checked against the
-# oracle), a 2-rank rehearsal of the multi-GPU path on the one GPU.  Outputs under gpurun_out/gate/.
+# Round gate on the GPU box: GPU tests, smoke, every bench config (the driver's own 20-step command first; C2 with ALL
+# arenas checked against the oracle), the self-started 2-rank form of bench.py on the one GPU.  Outputs: gpurun_out/gate/.
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/gate
@@ -7,11 +7,14 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gate/pytest.l
 tail -3 gpurun_out/gate/pytest.log
 timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/gate/smoke.log 2>&1 || { tail -20 gpurun_out/gate/smoke.log; exit 1; }
 tail -1 gpurun_out/gate/smoke.log
-for c in c2 c3 c4 c5; do timeout -k 10 400 python bench.py --config $c > gpurun_out/gate/bench_$c.json; done
-timeout -k 10 600 python bench.py --cpu-sample-arenas 65536 > gpurun_out/gate/bench_c2_all_arenas.json
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 200 --backend gloo --force-device 0 > gpurun_out/gate/bench_2rank_rehearsal.json 2> gpurun_out/gate/bench_2rank_rehearsal.err
+timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/gate/bench_c2_driver_20steps.json
+for c in c2 c3 c4 c5; do timeout -k 10 400 python bench.py --config $c > gpurun_out/gate/bench_${c}_default.json; done
+timeout -k 10 600 python bench.py --cpu-sample-arenas 65536 > gpurun_out/gate/bench_c2_all_arenas_checked.json
+timeout -k 10 300 python bench.py --gpus 2 --steps 200 --backend gloo --force-device 0 > gpurun_out/gate/bench_2rank_rehearsal.json 2> gpurun_out/gate/bench_2rank_rehearsal.err
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/gate/bench_*.json')):
-    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, '%.4g'%d['value'], d['n_gpus'], d['events'].get('flagged'), d.get('parity'), (d.get('cpu_baseline') or {}).get('value'))
+    d=json.loads(open(f).read().strip().splitlines()[-1]); p=d.get('parity') or {}
+    print(f, '%.4g'%d['value'], 'gpus', d['n_gpus'], 'steps', d['steps'], 'kernel ms/launch', d['roofline']['kernel_ms_per_launch'], 'frac', d['roofline']['frac'],
+          'traffic', d['roofline']['traffic'], 'parity', p.get('bit_identical'), p.get('arenas_checked'), p.get('host_streamed_bit_identical'), 'cpu', (d.get('cpu_baseline') or {}).get('value'))
 PY
