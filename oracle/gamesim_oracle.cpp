@@ -365,7 +365,11 @@ void scan_for_events(Arena &a, const int *checks, int n_checks, std::vector<Even
       }
     }
   }
-  std::sort(list.begin(), list.end(), Later());  // cpp:510
+  // cpp:510.  Tie order matters (equal-time events are common: tau clamps to 0) and std::sort gives no guarantee in
+  // general; the reference's list never holds more than E <= 15 events, and libstdc++'s std::sort is a plain
+  // insertion sort below 16 elements, hence stable: of equal-time events the later-inserted ends up nearer the
+  // back and is popped first (SURVEY Appendix B checked this against std::stable_sort on the compiled reference).
+  std::sort(list.begin(), list.end(), Later());
 }
 
 // updateSim, src/GameSim.cpp:126-171
