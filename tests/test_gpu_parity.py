@@ -646,3 +646,30 @@ def test_power_of_two_tau_folded_into_step_constants(rgp, oracle, tau_player, dt
     table = w.circle_controls(amp * 1.5, ph, w.step_times(K, dt))
     out, ref = run_both(rgp, oracle, n, x0, table, dt, variant=variant, tau_player=tau_player)
     check(out, ref, "tau_player=%g dt=%g" % (tau_player, dt))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
+def test_every_kernel_instantiation_matches_oracle(rgp, oracle, n):
+    """Every (team size, stepper variant, division mode) the library can launch, on one eventful workload.
+    The large-team kernels sit at the register limit and one build of k_step_hybrid2<7> faulted on the device
+    without any source-level cause: each instantiation is therefore exercised explicitly."""
+    from robo_game_py import workloads as w
+    B, K, dt = 160, 48, 0.02
+    x0, amp, ph = w.c2_inputs(B, n, seed=100 + n)
+    table = w.circle_controls(amp * 2.5, ph, w.step_times(K, dt))
+    modes = [("pow2+onestep", 0.1, 0.5, 2), ("pow2+markstein", 0.1, 0.5, 1), ("markstein", 0.13, 0.37, 2), ("ieee", 0.1, 0.5, 0)]
+    for name, tau_puck, tau_player, level in modes:
+        ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, want_damage=True,
+                               tau_puck=tau_puck, tau_player=tau_player)
+        assert ref["stats"]["resolved"] > 50
+        for variant in (1, 2, 3, 4):
+            sim = rgp.BatchedGameSim(B, n)
+            sim.set_variant(variant)
+            sim.set_fast_division(level)
+            sim.reset(dt, 1000, x0, 0.0, False, "", 0, tau_puck, tau_player)
+            got = sim.run_table(table, chunk_steps=K)
+            what = "n=%d variant=%d %s" % (n, variant, name)
+            assert_same(got, ref["state"], what)
+            assert_same(sim.damage().reshape(4 * n * n, B), ref["damage"], what + " damage")
+            assert sim.counters()["resolved"] == ref["stats"]["resolved"], what
+            sim.close()
