@@ -351,8 +351,10 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
   a.inv_tau_player = 1.0 / s->tau_player; a.inv_tau_puck = 1.0 / s->tau_puck;   // host IEEE division
   a.m_player = s->m_player; a.m_puck = s->m_puck;
-  a.le_pp = sqrt_threshold(kRPlayer + kRPlayer, false); a.le_pk = sqrt_threshold(kRPlayer + kRPuck, false);
-  a.lt_pp = sqrt_threshold(kRPlayer + kRPlayer, true);  a.lt_pk = sqrt_threshold(kRPlayer + kRPuck, true);
+  // the radii are compile-time constants: search the four thresholds once per process, not per launch
+  static const double le_pp = sqrt_threshold(kRPlayer + kRPlayer, false), le_pk = sqrt_threshold(kRPlayer + kRPuck, false);
+  static const double lt_pp = sqrt_threshold(kRPlayer + kRPlayer, true), lt_pk = sqrt_threshold(kRPlayer + kRPuck, true);
+  a.le_pp = le_pp; a.le_pk = le_pk; a.lt_pp = lt_pp; a.lt_pk = lt_pk;
   {
     const double rp = kRPlayer, rk = kRPuck;
     a.push101_pp = (1.01 * rp) / (rp + rp); a.push101_plk = (1.01 * rp) / (rp + rk); a.push101_pkk = (1.01 * rk) / (rp + rk);
