@@ -192,11 +192,21 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
   // columns (two discs, two axes).  Walls stay dense and tight: discs slide along walls for many
   // steps without touching, and a widened wall test would flag every one of those steps.
   const int we = p.watch_every;
-  double vb = 0.0;
+  // Speed bound of a PAIR: the two largest per-disc bounds s1 >= s2, s_e = hypot(|vx|max, |vy|max) (rounded up), so
+  // the distance of any pair changes by at most travel = 1.25*(we-1)*dt_col*(s1 + s2) between two checks -- never more
+  // than the 2*sqrt(2)*vb of the per-axis bound vb it replaces, and typically 0.6 of it: nearly all of C2's false
+  // alarms are pairs inside the shell between the true and the widened radius.
+  double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-  for (int c = 0; c < M; ++c) vb = __builtin_fmax(vb, __builtin_fmax(__builtin_fabs(vel[c]), __builtin_fabs(u[c])));
-  const double travel = 1.25 * (double)(we - 1) * dt_col * vb;
-  const double grow = 2.0 * 1.4142135623730951 * travel;    // pair distance: two discs, Euclidean
+  for (int e = 0; e < E; ++e) {
+    const double cx = __builtin_fmax(__builtin_fabs(vel[2 * e]), __builtin_fabs(u[2 * e]));
+    const double cy = __builtin_fmax(__builtin_fabs(vel[2 * e + 1]), __builtin_fabs(u[2 * e + 1]));
+    const double se = __builtin_sqrt(__builtin_fma(cx, cx, cy * cy)) * (1.0 + 1.0e-12);
+    const double lo = __builtin_fmin(s1, se);
+    s1 = __builtin_fmax(s1, se);
+    s2 = __builtin_fmax(s2, lo);
+  }
+  const double grow = 1.25 * (double)(we - 1) * dt_col * (s1 + s2) * (1.0 + 1.0e-12);   // pair distance: two discs, Euclidean
   const double xthr_pl = kX / 2.0 - kRPlayer - kWatchSlack, ythr_pl = kY / 2.0 - kRPlayer - kWatchSlack;
   const double xthr_pk = kX / 2.0 - kRPuck - kWatchSlack, ythr_pk = kY / 2.0 - kRPuck - kWatchSlack;
   const double rpp = 2.0 * kRPlayer + grow, rpk = kRPlayer + kRPuck + grow;
@@ -325,12 +335,17 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
   }
   // sparse pair watch, see lane_step; vb must cover BOTH axes of the arena (pair distances mix them)
   const int we = p.watch_every;
-  double vb = 0.0;
+  double s1 = 0.0, s2 = 0.0;                                // the two largest per-disc speed bounds, see lane_step
 #pragma unroll
-  for (int e = 0; e < E; ++e) vb = __builtin_fmax(vb, __builtin_fmax(__builtin_fabs(vel[e]), __builtin_fabs(u[e])));
-  vb = __builtin_fmax(vb, quad_xor1(vb));
-  const double travel = 1.25 * (double)(we - 1) * dt_col * vb;
-  const double grow = 2.0 * 1.4142135623730951 * travel;
+  for (int e = 0; e < E; ++e) {
+    const double c = __builtin_fmax(__builtin_fabs(vel[e]), __builtin_fabs(u[e]));
+    const double cc = c * c;
+    const double se = __builtin_sqrt(cc + quad_xor1(cc)) * (1.0 + 1.0e-12);   // both lanes of the arena: the same sum
+    const double lo = __builtin_fmin(s1, se);
+    s1 = __builtin_fmax(s1, se);
+    s2 = __builtin_fmax(s2, lo);
+  }
+  const double grow = 1.25 * (double)(we - 1) * dt_col * (s1 + s2) * (1.0 + 1.0e-12);
   const double half_extent = ax == 0 ? kX / 2.0 : kY / 2.0;
   const double thr_pl = half_extent - kRPlayer - kWatchSlack, thr_pk = half_extent - kRPuck - kWatchSlack;
   const double rpp = 2.0 * kRPlayer + grow, rpk = kRPlayer + kRPuck + grow;
