@@ -158,6 +158,10 @@ struct PoolQueue {                                           // lives in LDS beh
   int pend[kPoolWaves];
   unsigned seq[kPoolSlots];
   unsigned long long task[kPoolSlots];
+  unsigned fin[kPoolSlots];                                  // asynchronous form: steps completed by the wave pass, per arena
+  int front[kPoolWaves];                                     // asynchronous form: step count of each wavefront's most advanced arena
+  int lastk[kPoolSlots];                                     // asynchronous form: the arena's last wave-pass step ...
+  unsigned char streak[kPoolSlots];                          // ... and how many consecutive steps up to it had a collision
 };
 
 template <typename T>
@@ -172,7 +176,13 @@ __device__ __forceinline__ unsigned long long pool_pack(int local, int k, unsign
 }
 
 // One round: claims up to GPW tickets and runs them.  Returns false when the queue had nothing to claim.
-template <int N, int FAST>
+#ifndef GSIM_POOL_LAGMAX
+#define GSIM_POOL_LAGMAX 32
+#endif
+#ifndef GSIM_POOL_STREAK
+#define GSIM_POOL_STREAK 2
+#endif
+template <int N, int FAST, bool ASYNC>
 __device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, const GridView<N, false> &G, long long wg_a0, int lane,
                                            int grp, int lg) {
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
@@ -209,13 +219,39 @@ __device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, cons
   }
   const int local = (int)(payload & 255ull);
   wg_acquire();                                              // the arenas' state, written by the other wavefronts of this CU
+  bool ev = false;
   if (grp < take) {
     const int kk = (int)((payload >> 8) & 0x3FFFFFFull);
     const unsigned dm = (unsigned)((payload >> 34) & 0xFFFFull) | ((unsigned)((payload >> 50) & 63ull) << 16);
-    arena_step_group<N, GW, FAST, false, false>(p, p.ctl + (long long)kk * p.ctl_stride, wg_a0 + local, G, lg, lane - lg, dm);
+    ev = arena_step_group<N, GW, FAST, false, false>(p, p.ctl + (long long)kk * p.ctl_stride, wg_a0 + local, G, lg, lane - lg, dm);
   }
   wg_release();                                              // results stored before the home wavefront is told
-  if (grp < take && lg == 0) __hip_atomic_fetch_add(&Q->pend[local >> 6], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (grp < take && lg == 0) {
+    const int kk = (int)((payload >> 8) & 0x3FFFFFFull);
+    if (!ASYNC) {
+      __hip_atomic_fetch_add(&Q->pend[local >> 6], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      // Lasting contact (a puck pushed along, discs pressed together): GSIM_POOL_STREAK steps in a row that each
+      // had a collision.  Such an arena would be flagged by every lane pass and make its wavefront wait for
+      // every one of its steps; instead its next step is posted right here and it stays in the wave pass, at
+      // the wave pass' own pace, until a step goes by without a collision (or it gets ahead of its wavefront).
+      // Bit 31 of the completion word tells its lane to keep waiting.  Not while trajectories are recorded:
+      // the snapshot of step kk is taken by the arena's lane and must see the state of step kk.
+      const unsigned st = !ev ? 0u : (Q->lastk[local] == kk - 1 ? (unsigned)Q->streak[local] + 1u : 1u);
+      Q->streak[local] = (unsigned char)(st > 200u ? 200u : st);
+      Q->lastk[local] = kk;
+      const bool more = GSIM_POOL_STREAK > 0 && st >= (unsigned)GSIM_POOL_STREAK && p.traj == nullptr && kk + 1 < p.n_steps &&
+                        kk + 1 <= lds_ld(&Q->front[local >> 6]) + 1;
+      if (more) {
+        const unsigned tk = __hip_atomic_fetch_add(&Q->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&Q->task[tk & (kPoolSlots - 1)], pool_pack(local, kk + 1, 0xFFFFu | (1u << 16)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&Q->seq[tk & (kPoolSlots - 1)], tk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomicAdd(&p.counters[CNT_FLAGGED], 1ull);
+      }
+      __hip_atomic_store(&Q->fin[local], (unsigned)(kk + 1) | (more ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
   return true;
 }
 
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
       } else if (lent != 0) {
         break;                                               // nothing of its own: one round lent per step
       }
-      if (pool_round<N, FAST>(p, Q, G, wg_a0, lane, grp, lg)) { lent = 1; n_rounds++; }
+      if (pool_round<N, FAST, false>(p, Q, G, wg_a0, lane, grp, lg)) { lent = 1; n_rounds++; }
       else if (n == 0) break;
       else {                                                 // its remaining tasks are running on a sibling: at most one round's time
         __builtin_amdgcn_s_sleep(4);
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
   // this wavefront's arenas are done; keep serving its siblings until all four are (they are resident: bounded)
   if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   for (int waits = 0;;) {
-    if (pool_round<N, FAST>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; continue; }
+    if (pool_round<N, FAST, false>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; continue; }
     unsigned done = 0u;
     if (lane == 0) done = lds_ld(&Q->done);
     done = (unsigned)__shfl((int)done, 0);
@@ -302,6 +338,155 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
     atomicMax(&p.stamp_out[STAMP_MAX_TOTAL], t_all);
     atomicMax(&p.stamp_out[STAMP_MAX_WAVE], t_wave);
     atomicMax(&p.stamp_out[STAMP_MAX_ROUNDS], n_rounds);
+  }
+}
+
+// Asynchronous pooled hybrid.  Same queue, same tasks; what changes is who waits.  In k_step_pool a wavefront
+// runs its flagged arenas' rounds right after its lane pass, so most rounds hold one or two arenas (a round
+// is a chain of ~50 dependent RK4 sub-steps: it costs the same ~40 k cycles with one arena as with GPW) and
+// the 60-odd unflagged arenas of the wavefront wait for it.  Here every LANE keeps its own step count: a lane
+// whose arena was flagged posts the task and sits out lane passes until the task's completion word shows up;
+// the other lanes of the wavefront go on with their next steps.  Tasks collect in the queue until a round
+// is full (or the oldest one has been seen waiting at two consecutive looks, or the wavefront has nothing
+// else to do), so the rounds run full, and nobody but the flagged arena itself is delayed by it.  A
+// wavefront ends when each of its arenas has done its n_steps; the lag a lane collects (one or two lane
+// passes per flagged step) is what the asynchrony costs.  Arithmetic per arena-step: lane_step or
+// arena_step_group, both unchanged -- the order in which arena-steps of DIFFERENT arenas are run has no
+// influence on any value.
+#ifndef GSIM_POOL_AGE
+#define GSIM_POOL_AGE 1
+#endif
+#ifndef GSIM_POOL_BUSYMAX
+#define GSIM_POOL_BUSYMAX 0                                  // 0: a round's worth (GPW)
+#endif
+#ifndef GSIM_POOL_FEW
+#define GSIM_POOL_FEW 4
+#endif
+template <int N, int MODE>
+__global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
+  constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
+  extern __shared__ double lds[];
+  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grp = lane / GW, lg = lane % GW;
+  const long long wg_a0 = (long long)blockIdx.x * (64 * kPoolWaves);
+  const long long a = wg_a0 + threadIdx.x;
+  const bool mine = a < p.B;
+  const GridView<N, false> G{lds + (wave * GPW + grp) * WaveLayout<N>::DOUBLES, nullptr GSIM_GRID_DBG(p)};
+  PoolQueue *Q = (PoolQueue *)(lds + kPoolWaves * GPW * WaveLayout<N>::DOUBLES);
+  if (threadIdx.x < kPoolSlots) { Q->seq[threadIdx.x] = 0u; Q->fin[threadIdx.x] = 0u; Q->streak[threadIdx.x] = 0; Q->lastk[threadIdx.x] = -2; }
+  if (threadIdx.x < kPoolWaves) { Q->pend[threadIdx.x] = 0; Q->front[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) { Q->tail = 0u; Q->head = 0u; Q->done = 0u; }
+  __syncthreads();
+  unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, t_begin = 0;
+  if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
+  const int K = p.n_steps;
+  int kl = 0;                                                // steps this lane's arena has completed
+  bool busy = false;                                         // its step kl is with the wave pass
+  unsigned seen_head = 0xFFFFFFFFu;
+  int seen_times = 0, waits = 0;
+  unsigned long long n_iter = 0;
+  for (;;) {
+    // completions of posted tasks
+    unsigned fw = 0u;
+    if (busy) fw = lds_ld(&Q->fin[threadIdx.x]);
+    const int fk = (int)(fw & 0x7FFFFFFFu);
+    const bool moved = busy && fk > kl;
+    if (__ballot(moved) != 0ull) wg_acquire();               // those arenas' state, stored by whoever ran them
+    if (moved) {
+      if ((fw >> 31) == 0u) { busy = false; snapshot_state<N>(p, a, fk - 1, 0, 1); }   // (a step that is followed up: no trajectories then)
+      kl = fk;
+    }
+    const bool active = mine && !busy && kl < K;
+    const unsigned long long am = __ballot(active);
+    if (am == 0ull && __ballot(busy) == 0ull) break;         // every arena of this wavefront has done its steps
+    // Lag bound: an arena GSIM_POOL_LAGMAX steps behind the most advanced arena of its wavefront is waited for
+    // (no lane pass until it is back), so a wavefront runs at most n_steps + GSIM_POOL_LAGMAX lane passes however
+    // often single arenas of it are flagged; arenas in lasting contact make their wavefront run in step with them.
+    int f = mine ? kl : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int g = __shfl_xor(f, o); f = g > f ? g : f; }
+    if (lane == 0) __hip_atomic_store(&Q->front[wave], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long bm = __ballot(busy);
+    const bool hold = __ballot(busy && f - kl >= GSIM_POOL_LAGMAX) != 0ull ||
+                      __builtin_popcountll(bm) >= (GSIM_POOL_BUSYMAX > 0 ? GSIM_POOL_BUSYMAX : GPW);
+    unsigned long long t0 = 0, t1 = 0;
+    if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
+    unsigned discmask = 0xFFFFu | (1u << 16);                // a step posted without a lane pass: every disc, from column 1
+    bool slow = false;
+    // a lane pass costs the same for one arena as for 64: the last few stragglers go through the wave pass
+    const bool few = p.traj == nullptr && __builtin_popcountll(am) <= GSIM_POOL_FEW;
+    if (am != 0ull && !few && !hold) {
+      n_iter++;
+      unsigned dm = 0u;
+      slow = active && lane_step<N, MODE>(p, p.ctl + (long long)kl * p.ctl_stride, a, dm);
+      if (slow) discmask = dm;
+      if (active && !slow) { snapshot_state<N>(p, a, kl, 0, 1); kl++; }
+    }
+    const bool post = slow || (few && !hold && active);
+    const unsigned long long m = __ballot(post);
+    if (m != 0ull) {
+      const int n = __builtin_popcountll(m);
+      wg_release();                                          // these arenas' state as of their step is stored before they are offered
+      unsigned tk = 0u;
+      if (lane == 0) {
+        atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)n);
+        tk = __hip_atomic_fetch_add(&Q->tail, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      tk = (unsigned)__shfl((int)tk, 0) + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (post) {
+        __hip_atomic_store(&Q->task[tk & (kPoolSlots - 1)], pool_pack((int)threadIdx.x, kl, discmask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&Q->seq[tk & (kPoolSlots - 1)], tk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        busy = true;
+      }
+    }
+    if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
+    // serve: a full round, or a task that has been seen waiting before, or anything at all when this
+    // wavefront cannot take a lane pass now
+    const bool can_step = !hold && __builtin_popcountll(__ballot(mine && !busy && kl < K)) > (p.traj == nullptr ? GSIM_POOL_FEW : 0);
+    bool served = false;
+    for (;;) {
+      unsigned h = 0u;
+      int avail = 0;
+      if (lane == 0) { h = lds_ld(&Q->head); avail = (int)(lds_ld(&Q->tail) - h); }
+      h = (unsigned)__shfl((int)h, 0);
+      avail = __shfl(avail, 0);
+      if (avail <= 0) { seen_times = 0; seen_head = 0xFFFFFFFFu; break; }
+      if (h == seen_head) seen_times++; else { seen_head = h; seen_times = 1; }
+      if (avail < GPW && can_step && seen_times < GSIM_POOL_AGE) break;
+      if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; served = true; }
+      seen_times = 0; seen_head = 0xFFFFFFFFu;
+      if (can_step) break;                                   // one round per lane pass while there are lane passes to do
+    }
+    if (!can_step && !served && m == 0ull) {                 // what this wavefront waits for is running elsewhere
+      if (__ballot(busy && (int)(lds_ld(&Q->fin[threadIdx.x]) & 0x7FFFFFFFu) > kl) == 0ull) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++waits > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
+      }
+    }
+    if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
+  }
+  // this wavefront's arenas are done; keep serving its siblings until all four are (they are resident: bounded)
+  if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int spins = 0;;) {
+    if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; continue; }
+    unsigned done = 0u;
+    if (lane == 0) done = lds_ld(&Q->done);
+    done = (unsigned)__shfl((int)done, 0);
+    if (done >= (unsigned)kPoolWaves) break;
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
+  }
+  if (GSIM_STAMPS && p.stamps && lane == 0) {
+    const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
+    atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
+    atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
+    atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
+    atomicAdd(&p.stamp_out[STAMP_TOTAL], t_all);
+    atomicMax(&p.stamp_out[STAMP_MAX_TOTAL], t_all);
+    atomicMax(&p.stamp_out[STAMP_MAX_WAVE], t_wave);
+    atomicMax(&p.stamp_out[STAMP_MAX_ROUNDS], n_iter);   // here: lane passes of the slowest wavefront
   }
 }
 

@@ -460,7 +460,8 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // a disc outside the mask provably has no candidate in the first scan, so that scan is skipped;
 // bits 16..21 = first grid column that can hold a candidate (1 when unknown), where the first scans
 // start.
-// Returns without touching anything if the game is already decided (cpp:121-123).
+// Returns without touching anything if the game is already decided (cpp:121-123); the return value says
+// whether the step had any collision event.
 //
 // NOISE (w_stdev_ != 0): every RK4 of a player consumes 8 draws of the arena's tape in the reference's
 // call order -- populateStateGrid: column by column, A1..Bn (cpp:199-215); carryOutFirstCollision:
@@ -469,14 +470,14 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
 template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false, bool COH = false>
-__device__ void arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
+__device__ bool arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
                                  const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
   constexpr int E = L::E, PK = L::PK;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
   const long long B = p.B;
   double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
-  if (!(TAS < p.win && TBS < p.win)) return;                 // undecided(), cpp:57-60,121
+  if (!(TAS < p.win && TBS < p.win)) return false;           // undecided(), cpp:57-60,121
   const double t0 = gld_at<COH>(p.tcur, a, p.n_tcur);
   const double dt = p.dt, dt_col = p.dt_col;
   const double *tape = NOISE ? p.tape + a * (long long)p.tape_len : nullptr;
@@ -819,6 +820,7 @@ __device__ void arena_step_group(const StepArgs &p, const double *__restrict__ c
     atomicAdd(&p.stamp_out[STAMP_COMMIT], ts4 - ts3);
     atomicAdd(&p.stamp_out[STAMP_ARENAS], 1ull);
   }
+  return had_events;                                         // group-uniform: the step found at least one collision
 }
 
 }  // namespace gsim

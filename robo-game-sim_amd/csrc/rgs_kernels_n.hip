@@ -22,17 +22,26 @@ hipError_t launch_hybrid_mode(const StepArgs &args, hipStream_t stream) {
   return hipGetLastError();
 }
 
+#ifndef GSIM_POOL_ASYNC
+#define GSIM_POOL_ASYNC 1
+#endif
+#if GSIM_POOL_ASYNC
+#define GSIM_POOL_KERNEL k_step_apool
+#else
+#define GSIM_POOL_KERNEL k_step_pool
+#endif
+
 template <int MODE>
 hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + 64 * kPoolWaves - 1) / (64 * kPoolWaves);
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW * kPoolWaves + sizeof(PoolQueue);
   static bool attr_set = false;                              // > 64 KB of dynamic LDS has to be asked for once
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_step_pool<N, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)GSIM_POOL_KERNEL<N, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_step_pool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
+  hipLaunchKernelGGL((GSIM_POOL_KERNEL<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
   return hipGetLastError();
 }
 
