@@ -25,10 +25,18 @@ hipError_t launch_hybrid_mode(const StepArgs &args, hipStream_t stream) {
 #ifndef GSIM_POOL_ASYNC
 #define GSIM_POOL_ASYNC 1
 #endif
-#if GSIM_POOL_ASYNC
+#ifndef GSIM_POOL_DUO
+#define GSIM_POOL_DUO 0
+#endif
+#if GSIM_POOL_DUO
+#define GSIM_POOL_KERNEL k_step_duo
+constexpr int kPoolThreads = 128 * kPoolWaves;
+#elif GSIM_POOL_ASYNC
 #define GSIM_POOL_KERNEL k_step_apool
+constexpr int kPoolThreads = 64 * kPoolWaves;
 #else
 #define GSIM_POOL_KERNEL k_step_pool
+constexpr int kPoolThreads = 64 * kPoolWaves;
 #endif
 
 template <int MODE>
@@ -41,7 +49,7 @@ hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((GSIM_POOL_KERNEL<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
+  hipLaunchKernelGGL((GSIM_POOL_KERNEL<N, MODE>), dim3((unsigned)blocks), dim3(kPoolThreads), lds, stream, args);
   return hipGetLastError();
 }
 
