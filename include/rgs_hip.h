@@ -43,8 +43,10 @@ enum {
   RGS_VARIANT_WAVE = 1,      /* one wavefront owns one arena, grid in LDS */
   RGS_VARIANT_HYBRID = 2,    /* lane-per-arena streaming pass + LDS event pass */
   RGS_VARIANT_HYBRID2 = 3,   /* the same with two lanes (x chains, y chains) per arena */
-  RGS_VARIANT_POOL = 4       /* HYBRID whose flagged arena-steps go through one chip-wide queue: full event-pass rounds,
-                                wavefronts help each other and the early finishers serve the queue until the launch ends */
+  RGS_VARIANT_POOL = 4,      /* HYBRID with four wavefronts per workgroup whose flagged arena-steps go through one queue in
+                                LDS: fuller event-pass rounds, wavefronts help each other, early finishers keep serving */
+  RGS_VARIANT_APOOL = 5      /* POOL with per-arena step counts: a flagged arena's lane sits out lane passes until its step
+                                is back from the event pass, the rest of its wavefront goes on (bounded lag) */
 };
 
 /* Human-readable text for the most recent failure on this thread. */

@@ -490,138 +490,6 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
   }
 }
 
-// Duo: the asynchronous pooled hybrid with the two passes on DIFFERENT wavefronts of the workgroup.  Eight wavefronts
-// per workgroup, two per SIMD: wavefronts 0-3 run nothing but lane passes for the workgroup's 256 arenas (per-lane
-// step counts as in k_step_apool: a flagged arena's lane posts the step and sits out until it is back), wavefronts
-// 4-7 run nothing but wave-pass rounds from the queue.  A wave-pass round is a latency-bound chain (~8 cycles per
-// instruction) and the lane pass of a lone wavefront leaves a quarter of the SIMD's FP64 issue slots empty; with the
-// two on one SIMD the rounds run in those gaps instead of in the lane wavefront's own time.  Needs the kernel in 256
-// registers (512 threads per workgroup), which the one-lane pass of n <= 2 fits.
-#ifndef GSIM_DUO_MINFILL
-#define GSIM_DUO_MINFILL 1
-#endif
-template <int N, int MODE>
-__global__ __launch_bounds__(128 * kPoolWaves, 1) void k_step_duo(StepArgs p) {
-  constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
-  extern __shared__ double lds[];
-  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int grp = lane / GW, lg = lane % GW;
-  const long long wg_a0 = (long long)blockIdx.x * (64 * kPoolWaves);
-  PoolQueue *Q = (PoolQueue *)(lds + kPoolWaves * GPW * WaveLayout<N>::DOUBLES);
-  if (threadIdx.x < kPoolSlots) { Q->seq[threadIdx.x] = 0u; Q->fin[threadIdx.x] = 0u; Q->streak[threadIdx.x] = 0; Q->lastk[threadIdx.x] = -2; }
-  if (threadIdx.x < kPoolWaves) { Q->pend[threadIdx.x] = 0; Q->front[threadIdx.x] = 0; }
-  if (threadIdx.x == 0) { Q->tail = 0u; Q->head = 0u; Q->done = 0u; }
-  __syncthreads();
-  unsigned long long t_lane = 0, t_wave = 0, n_rounds = 0, n_iter = 0, t_begin = 0;
-  if (GSIM_STAMPS && p.stamps) t_begin = __builtin_amdgcn_s_memtime();
-  if (wave >= kPoolWaves) {
-    // ---- wave-pass wavefront ----
-    const GridView<N, false> G{lds + ((wave - kPoolWaves) * GPW + grp) * WaveLayout<N>::DOUBLES, nullptr GSIM_GRID_DBG(p)};
-    unsigned seen_head = 0xFFFFFFFFu;
-    int seen_times = 0;
-    for (int spins = 0;;) {
-      unsigned h = 0u, done = 0u;
-      int avail = 0;
-      if (lane == 0) { h = lds_ld(&Q->head); avail = (int)(lds_ld(&Q->tail) - h); done = lds_ld(&Q->done); }
-      h = (unsigned)__shfl((int)h, 0);
-      avail = __shfl(avail, 0);
-      done = (unsigned)__shfl((int)done, 0);
-      if (avail > 0) {
-        if (h == seen_head) seen_times++; else { seen_head = h; seen_times = 1; }
-        if (avail >= GSIM_DUO_MINFILL || seen_times > 8 || done != 0u) {
-          unsigned long long t0 = 0;
-          if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
-          if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) n_rounds++;
-          if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t0;
-          seen_head = 0xFFFFFFFFu; seen_times = 0; spins = 0;
-          continue;
-        }
-      } else if (done >= (unsigned)kPoolWaves) {
-        break;                                               // every lane wavefront is through and nothing is queued
-      }
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
-    }
-  } else {
-    // ---- lane-pass wavefront ----
-    const long long a = wg_a0 + threadIdx.x;
-    const bool mine = a < p.B;
-    const int K = p.n_steps;
-    int kl = 0;                                              // steps this lane's arena has completed
-    bool busy = false;                                       // its step kl (or a later one) is with the wave pass
-    int waits = 0;
-    for (;;) {
-      unsigned fw = 0u;
-      if (busy) fw = lds_ld(&Q->fin[threadIdx.x]);
-      const int fk = (int)(fw & 0x7FFFFFFFu);
-      const bool moved = busy && fk > kl;
-      if (__ballot(moved) != 0ull) wg_acquire();             // those arenas' state, stored by whoever ran them
-      if (moved) {
-        if ((fw >> 31) == 0u) { busy = false; snapshot_state<N>(p, a, fk - 1, 0, 1); }
-        kl = fk;
-      }
-      const bool active = mine && !busy && kl < K;
-      const unsigned long long am = __ballot(active);
-      if (am == 0ull && __ballot(busy) == 0ull) break;       // every arena of this wavefront has done its steps
-      int f = mine ? kl : 0;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { const int g = __shfl_xor(f, o); f = g > f ? g : f; }
-      if (lane == 0) __hip_atomic_store(&Q->front[wave], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const bool hold = __ballot(busy && f - kl >= GSIM_POOL_LAGMAX) != 0ull;
-      const bool few = p.traj == nullptr && __builtin_popcountll(am) <= GSIM_POOL_FEW;
-      unsigned long long t0 = 0;
-      if (GSIM_STAMPS && p.stamps) t0 = __builtin_amdgcn_s_memtime();
-      unsigned discmask = 0xFFFFu | (1u << 16);              // a step posted without a lane pass: every disc, from column 1
-      bool slow = false;
-      if (am != 0ull && !few && !hold) {
-        n_iter++;
-        unsigned dm = 0u;
-        slow = active && lane_step<N, MODE>(p, p.ctl + (long long)kl * p.ctl_stride, a, dm);
-        if (slow) discmask = dm;
-        if (active && !slow) { snapshot_state<N>(p, a, kl, 0, 1); kl++; }
-      }
-      const bool post = slow || (few && !hold && active);
-      const unsigned long long m = __ballot(post);
-      if (m != 0ull) {
-        const int n = __builtin_popcountll(m);
-        wg_release();                                        // these arenas' state as of their step is stored before they are offered
-        unsigned tk = 0u;
-        if (lane == 0) {
-          atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)n);
-          tk = __hip_atomic_fetch_add(&Q->tail, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        tk = (unsigned)__shfl((int)tk, 0) + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (post) {
-          __hip_atomic_store(&Q->task[tk & (kPoolSlots - 1)], pool_pack((int)threadIdx.x, kl, discmask), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&Q->seq[tk & (kPoolSlots - 1)], tk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          busy = true;
-        }
-      }
-      if (GSIM_STAMPS && p.stamps) t_lane += __builtin_amdgcn_s_memtime() - t0;
-      const bool can_step = !hold && __builtin_popcountll(__ballot(mine && !busy && kl < K)) > (p.traj == nullptr ? GSIM_POOL_FEW : 0);
-      if (!can_step && m == 0ull) {                          // waiting for the wave-pass wavefronts
-        if (__ballot(busy && (int)(lds_ld(&Q->fin[threadIdx.x]) & 0x7FFFFFFFu) > kl) == 0ull) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++waits > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
-        }
-      }
-    }
-    if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  if (GSIM_STAMPS && p.stamps && lane == 0) {
-    const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
-    atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
-    atomicAdd(&p.stamp_out[STAMP_WAVE], t_wave);
-    atomicAdd(&p.stamp_out[STAMP_ROUNDS], n_rounds);
-    atomicAdd(&p.stamp_out[STAMP_TOTAL], t_all);
-    atomicMax(&p.stamp_out[STAMP_MAX_TOTAL], t_all);
-    atomicMax(&p.stamp_out[STAMP_MAX_WAVE], t_wave);
-    atomicMax(&p.stamp_out[STAMP_MAX_ROUNDS], n_iter);
-  }
-}
-
 // Hybrid with two lanes per arena (gsim_lane.hpp, lane_step_split): 32 arenas per wave.
 // Which team sizes use the split grid in the two-lane hybrid: +14..18 % at 6v6/7v7 where it doubles
 // the grids per block; at 4v4 it makes three 20-lane groups fit; 5v5 (two grids fit either way) loses
@@ -746,7 +614,7 @@ __global__ void k_record(const double *state, const double *tcur, const double *
 
 
 // What the host needs from one n, resolved at run time through gsim_ops(n).
-enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4 };
+enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5 };
 
 struct GsimOps {
   // kind: LaunchKind; mode: DivMode (hybrids) or the wave pass division level 0/1/3 (wave kernels)

@@ -427,7 +427,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   // kernels need 65 536 arenas to put a wavefront on every SIMD, the two-lane one 32 768); the wave-per-arena kernel
   // spreads even a few hundred arenas over the whole chip and is modelled as B / (t0 + B / saturated rate) through its
   // 1 024- and 65 536-arena points.  Launches of few steps are tail-dominated and have their own table ("short").
-  // The pooled hybrid needs its 256-arena workgroups (141 KB of LDS) resident all at once: one per CU at most.
+  // The pooled hybrids' workgroups (256 arenas, ~140 KB of LDS: one per CU) are self-contained; with more of them than
+  // CUs the later ones start as the earlier ones end, like the blocks of the other kernels.
   const int regime = n_steps <= 64 ? 0 : 1;
   const double Bd = (double)s->B;
   auto hybrid_rate = [&](int kern) {
@@ -437,7 +438,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     return r32 + (r65 - r32) * (Bd - 32768.0) / 32768.0;
   };
   const double est_one = hybrid_rate(1), est_two = hybrid_rate(2);
-  const double est_pool = (s->B + 255) / 256 <= (long long)s->n_cus ? hybrid_rate(3) : 0.0;
+  const double est_pool = hybrid_rate(3), est_apool = hybrid_rate(4);
   double est_wave = 0.0;
   {
     const double sat = kAutoRate[regime][0][1][s->n], r1k = kAutoWave1k[regime][s->n];
@@ -450,6 +451,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   double best_rate = est_one;
   if (est_two > best_rate) { best = RGS_VARIANT_HYBRID2; best_rate = est_two; }
   if (est_pool > best_rate) { best = RGS_VARIANT_POOL; best_rate = est_pool; }
+  if (est_apool > best_rate) { best = RGS_VARIANT_APOOL; best_rate = est_apool; }
   if (est_wave > best_rate) { best = RGS_VARIANT_WAVE; best_rate = est_wave; }
   const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : best);
   const bool fast = use_fast_division(s);
@@ -472,6 +474,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
   }
   if (variant == RGS_VARIANT_POOL && n_steps < (1 << 26)) return launch_kind(s, a, LAUNCH_POOL, div_mode);
+  if (variant == RGS_VARIANT_APOOL && n_steps < (1 << 26)) return launch_kind(s, a, LAUNCH_APOOL, div_mode);
   if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
   return launch_kind(s, a, LAUNCH_WAVE, !fast ? 0 : (s->one_step_ok ? 3 : 1));
 
@@ -829,7 +832,7 @@ int rgs_debug_check_guards(rgs_sim *s) {
 }
 
 int rgs_set_variant(rgs_sim *s, int variant) {
-  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_POOL) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
+  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_APOOL) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
   return RGS_OK;
 }

@@ -22,34 +22,19 @@ hipError_t launch_hybrid_mode(const StepArgs &args, hipStream_t stream) {
   return hipGetLastError();
 }
 
-#ifndef GSIM_POOL_ASYNC
-#define GSIM_POOL_ASYNC 1
-#endif
-#ifndef GSIM_POOL_DUO
-#define GSIM_POOL_DUO 0
-#endif
-#if GSIM_POOL_DUO
-#define GSIM_POOL_KERNEL k_step_duo
-constexpr int kPoolThreads = 128 * kPoolWaves;
-#elif GSIM_POOL_ASYNC
-#define GSIM_POOL_KERNEL k_step_apool
-constexpr int kPoolThreads = 64 * kPoolWaves;
-#else
-#define GSIM_POOL_KERNEL k_step_pool
-constexpr int kPoolThreads = 64 * kPoolWaves;
-#endif
-
-template <int MODE>
+template <int MODE, bool ASYNC>
 hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + 64 * kPoolWaves - 1) / (64 * kPoolWaves);
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW * kPoolWaves + sizeof(PoolQueue);
-  static bool attr_set = false;                              // > 64 KB of dynamic LDS has to be asked for once
+  const void *fn = ASYNC ? (const void *)k_step_apool<N, MODE> : (const void *)k_step_pool<N, MODE>;
+  static bool attr_set = false;                              // > 64 KB of dynamic LDS has to be asked for once (per instantiation)
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)GSIM_POOL_KERNEL<N, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((GSIM_POOL_KERNEL<N, MODE>), dim3((unsigned)blocks), dim3(kPoolThreads), lds, stream, args);
+  if (ASYNC) hipLaunchKernelGGL((k_step_apool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
+  else hipLaunchKernelGGL((k_step_pool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
   return hipGetLastError();
 }
 
@@ -83,10 +68,15 @@ hipError_t step(const StepArgs &args, hipStream_t stream, int kind, int mode) {
              : mode == DIV_MARKSTEIN ? launch_hybrid_mode<DIV_MARKSTEIN>(args, stream)
                                      : launch_hybrid_mode<DIV_IEEE>(args, stream);
     case LAUNCH_POOL:
-      return mode == DIV_POW2_ONESTEP ? launch_pool_mode<DIV_POW2_ONESTEP>(args, stream)
-             : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2>(args, stream)
-             : mode == DIV_MARKSTEIN ? launch_pool_mode<DIV_MARKSTEIN>(args, stream)
-                                     : launch_pool_mode<DIV_IEEE>(args, stream);
+      return mode == DIV_POW2_ONESTEP ? launch_pool_mode<DIV_POW2_ONESTEP, false>(args, stream)
+             : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2, false>(args, stream)
+             : mode == DIV_MARKSTEIN ? launch_pool_mode<DIV_MARKSTEIN, false>(args, stream)
+                                     : launch_pool_mode<DIV_IEEE, false>(args, stream);
+    case LAUNCH_APOOL:
+      return mode == DIV_POW2_ONESTEP ? launch_pool_mode<DIV_POW2_ONESTEP, true>(args, stream)
+             : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2, true>(args, stream)
+             : mode == DIV_MARKSTEIN ? launch_pool_mode<DIV_MARKSTEIN, true>(args, stream)
+                                     : launch_pool_mode<DIV_IEEE, true>(args, stream);
     case LAUNCH_HYBRID2:
       return mode == DIV_POW2_ONESTEP ? launch_hybrid2_mode<DIV_POW2_ONESTEP>(args, stream)
              : mode == DIV_PLAYER_POW2 ? launch_hybrid2_mode<DIV_PLAYER_POW2>(args, stream)

@@ -17,7 +17,7 @@ import struct
 import numpy as np
 
 from . import _lib
-from ._lib import RgsError, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_WAVE  # noqa: F401
+from ._lib import RgsError, VARIANT_APOOL, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_WAVE  # noqa: F401
 
 __all__ = ["GameSim", "BatchedGameSim", "SimStateView", "RgsError", "reset_arguments", "state_size",
            "log_record"]

@@ -18,7 +18,7 @@ RGS_ERR_HIP = -2
 RGS_ERR_UNSUPPORTED = -3
 RGS_ERR_NO_DEVICE = -4
 
-VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL = 0, 1, 2, 3, 4
+VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_APOOL = 0, 1, 2, 3, 4, 5
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p

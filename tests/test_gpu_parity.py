@@ -253,7 +253,7 @@ def test_c1_run_sim_loop_100_seconds(rgp, oracle):
     assert g.time() == o.time() and g.undecided() == o.undecided()
 
 
-VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid"), pytest.param(3, id="hybrid2"), pytest.param(4, id="pool")]
+VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid"), pytest.param(3, id="hybrid2"), pytest.param(4, id="pool"), pytest.param(5, id="apool")]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -449,7 +449,7 @@ def test_parameter_fuzz(rgp, oracle, seed):
             d = x0[:2] - s0[6 + 4 * e:8 + 4 * e, None]
             table[:, e] = (float(rng.uniform(2, 6)) * d / np.maximum(1e-9, np.sqrt((d * d).sum(0))))[None]
     ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=win, n_threads=8, want_damage=True, **phys)
-    for variant in (1, 2, 3, 4):
+    for variant in (1, 2, 3, 4, 5):
         sim = rgp.BatchedGameSim(B, n)
         sim.set_variant(variant)
         sim.reset(dt, win, x0, 0.0, False, "", 0, phys["tau_puck"], phys["tau_player"], phys["player_mass"], phys["puck_mass"])
@@ -464,7 +464,7 @@ def test_parameter_fuzz(rgp, oracle, seed):
         sim.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_pathological_inputs_neither_hang_nor_diverge(rgp, oracle, variant):
     """NaN / inf / 1e200 controls and states, dt = 0, a tiny tau: every loop of the kernels is bounded
     and every grid index clamped, so the step returns, and what it returns equals the oracle's result
@@ -492,7 +492,7 @@ def test_pathological_inputs_neither_hang_nor_diverge(rgp, oracle, variant):
                                                                       sorted(set(np.argwhere(~same)[:, 1].tolist()))[:10])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n", [2, 4])
 def test_in_kernel_trajectory_snapshots(rgp, oracle, n, variant):
     """State snapshots taken inside one fused launch equal the oracle's recorded trajectory."""
@@ -565,7 +565,7 @@ def oracle_from_state(oracle, n, st, table, dt, win=3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_division_guard_on_one_axis_only(rgp, oracle, variant):
     """A control far below the fast-division window on ONE axis trips the guard in one lane of the
     two-lane pass only; the arena must still be re-run from column 1 (an early wall bounce of another
@@ -662,7 +662,7 @@ def test_every_kernel_instantiation_matches_oracle(rgp, oracle, n):
         ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, want_damage=True,
                                tau_puck=tau_puck, tau_player=tau_player)
         assert ref["stats"]["resolved"] > 50
-        for variant in (1, 2, 3, 4):
+        for variant in (1, 2, 3, 4, 5):
             sim = rgp.BatchedGameSim(B, n)
             sim.set_variant(variant)
             sim.set_fast_division(level)

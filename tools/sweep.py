@@ -4,7 +4,7 @@
     python tools/sweep.py > gpurun_out/sweep_auto.json
 
 For every team size 1..7, every stepper variant (1 wave-per-arena, 2 one-lane hybrid, 3 two-lane hybrid,
-4 pooled hybrid), at 32 768 and 65 536 arenas (wave kernel also at 1 024, its launch-latency point), the C2-shaped
+4 pooled hybrid, 5 asynchronous pooled hybrid), at 32 768 and 65 536 arenas (wave kernel also at 1 024, its launch-latency point), the C2-shaped
 workload (bench.py --config c2) is timed as one fused launch of 500 steps ("long") and of 20 steps after 5 warm-up
 steps ("short", the tail-dominated regime).  tools/rates_to_header.py turns the JSON into
 robo-game-sim_amd/csrc/auto_rates.h, which is what rgs_hip.hip reads; nothing measured is typed into the library.
@@ -30,7 +30,7 @@ def run(n, variant, arenas, steps, warmup):
 def main():
     res = {"unit": "arena-steps/s", "workload": "bench.py --config c2 shape", "long": [500, 10], "short": [20, 5], "rates": []}
     for n in range(1, 8):
-        for variant in (1, 2, 3, 4):
+        for variant in (1, 2, 3, 4, 5):
             sizes = (1024, 32768, 65536) if variant == 1 else (32768, 65536)
             for arenas in sizes:
                 for regime, (k, w) in (("long", res["long"]), ("short", res["short"])):
