@@ -81,13 +81,14 @@ def parse_args(argv=None):
     ap.add_argument("--jam", action="store_true", help="diagnostic: drive every player towards the arena centre "
                     "(sustained contact, many 49-event steps): the hybrid's worst case")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
+    ap.add_argument("--dt", type=float, default=None, help="diagnostic / tools/sweep.py: override the preset's step length")
     args = ap.parse_args(argv)
     preset = PRESETS[args.config]
     if args.n_per_team is None:
         args.n_per_team = preset[0]
     if args.arenas is None:
         args.arenas = preset[1]
-    args.dt, args.win = preset[2], preset[3]
+    args.dt, args.win = (preset[2] if args.dt is None else args.dt), preset[3]
     if args.steps is None:
         args.steps = preset[4]
     if args.warmup is None:

@@ -426,13 +426,18 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   // here.  The hybrids are measured at 32 768 and 65 536 arenas (linear in between and below, flat above: the one-lane
   // kernels need 65 536 arenas to put a wavefront on every SIMD, the two-lane one 32 768); the wave-per-arena kernel
   // spreads even a few hundred arenas over the whole chip and is modelled as B / (t0 + B / saturated rate) through its
-  // 1 024- and 65 536-arena points.  Launches of few steps are tail-dominated and have their own table ("short").
+  // 1 024- and 65 536-arena points.  Launches of few steps are tail-dominated and have their own table ("short"); the
+  // share of arena-steps with events grows with the step length, so the table is measured at dt = 0.01 and 0.05 and the
+  // nearer one (in ratio) is used.
   // The pooled hybrids' workgroups (256 arenas, ~140 KB of LDS: one per CU) are self-contained; with more of them than
   // CUs the later ones start as the earlier ones end, like the blocks of the other kernels.
   const int regime = n_steps <= 64 ? 0 : 1;
+  int dtc = 0;                                               // the measured step length nearest to this handle's (in ratio)
+  for (int i = 1; i < kAutoDts; ++i)
+    if (std::fabs(std::log(s->dt / kAutoDt[i])) < std::fabs(std::log(s->dt / kAutoDt[dtc]))) dtc = i;
   const double Bd = (double)s->B;
   auto hybrid_rate = [&](int kern) {
-    const double r32 = kAutoRate[regime][kern][0][s->n], r65 = kAutoRate[regime][kern][1][s->n];
+    const double r32 = kAutoRate[dtc][regime][kern][0][s->n], r65 = kAutoRate[dtc][regime][kern][1][s->n];
     if (Bd <= 32768.0) return r32 * Bd / 32768.0;
     if (Bd >= 65536.0) return r65;
     return r32 + (r65 - r32) * (Bd - 32768.0) / 32768.0;
@@ -441,7 +446,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   const double est_pool = hybrid_rate(3), est_apool = hybrid_rate(4);
   double est_wave = 0.0;
   {
-    const double sat = kAutoRate[regime][0][1][s->n], r1k = kAutoWave1k[regime][s->n];
+    const double sat = kAutoRate[dtc][regime][0][1][s->n], r1k = kAutoWave1k[dtc][regime][s->n];
     if (sat > 0.0 && r1k > 0.0) {
       const double t0 = 1024.0 / r1k - 1024.0 / sat;           // microseconds
       est_wave = Bd / ((t0 > 0.0 ? t0 : 0.0) + Bd / sat);
