@@ -11,6 +11,10 @@ timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/ga
 for c in c2 c3 c4 c5; do timeout -k 10 400 python bench.py --config $c > gpurun_out/gate/bench_${c}_default.json; done
 timeout -k 10 600 python bench.py --cpu-sample-arenas 65536 > gpurun_out/gate/bench_c2_all_arenas_checked.json
 timeout -k 10 300 python bench.py --gpus 2 --steps 200 --backend gloo --force-device 0 > gpurun_out/gate/bench_2rank_rehearsal.json 2> gpurun_out/gate/bench_2rank_rehearsal.err
+if [ -f robo-game-sim_amd/csrc/librgs_hip_stamps.so ]; then   # in-kernel phase stamps of the driver's command (make SUFFIX=_stamps STAMPS=1)
+  RGS_LIB_SUFFIX=_stamps timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --stamps > gpurun_out/gate/bench_c2_driver_20steps_stamps.json
+  RGS_LIB_SUFFIX=_stamps timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --stamps --variant 2 > gpurun_out/gate/bench_c2_driver_20steps_stamps_hybrid.json
+fi
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/gate/bench_*.json')):
