@@ -145,3 +145,28 @@ def test_sim_state_view_has_the_reference_accessors(rgp):
         v.get_player_state("A", 3)
     with pytest.raises(TypeError):
         rgp.SimStateView(np.zeros(23))
+
+
+def test_auto_rate_header_is_what_the_committed_sweep_generates(tmp_path):
+    """csrc/auto_rates.h (all RGS_VARIANT_AUTO knows) must be tools/rates_to_header.py's output for the committed sweep."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "robo-game-sim_amd", "csrc", "auto_rates.h")
+    before = open(hdr).read()
+    try:
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "rates_to_header.py")], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=60)
+        assert out.returncode == 0, out.stderr.decode()
+        assert open(hdr).read() == before, "auto_rates.h is stale: re-run tools/rates_to_header.py and rebuild"
+    finally:
+        open(hdr, "w").write(before)
+    assert "kAutoRate[kAutoDts][2][5][2][8]" in before and "kAutoDt[kAutoDts] = {0.01, 0.05}" in before
+
+
+def test_bench_dt_override_keeps_the_presets():
+    import bench
+    a = bench.parse_args(["--config", "c2", "--dt", "0.05"])
+    assert a.dt == 0.05 and a.n_per_team == 2 and a.arenas == 65536 and a.steps == 1000
+    assert bench.parse_args(["--config", "c4"]).dt == 0.05 and bench.parse_args([]).dt == 0.01
