@@ -342,22 +342,24 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
 }
 
 // Asynchronous pooled hybrid.  Same queue, same tasks; what changes is who waits.  In k_step_pool a wavefront
-// runs its flagged arenas' rounds right after its lane pass, so most rounds hold one or two arenas (a round
-// is a chain of ~50 dependent RK4 sub-steps: it costs the same ~40 k cycles with one arena as with GPW) and
-// the 60-odd unflagged arenas of the wavefront wait for it.  Here every LANE keeps its own step count: a lane
-// whose arena was flagged posts the task and sits out lane passes until the task's completion word shows up;
-// the other lanes of the wavefront go on with their next steps.  Tasks collect in the queue until a round
-// is full (or the oldest one has been seen waiting at two consecutive looks, or the wavefront has nothing
-// else to do), so the rounds run full, and nobody but the flagged arena itself is delayed by it.  A
-// wavefront ends when each of its arenas has done its n_steps; the lag a lane collects (one or two lane
-// passes per flagged step) is what the asynchrony costs.  Arithmetic per arena-step: lane_step or
+// runs its flagged arenas' rounds right after its lane pass and the 60-odd unflagged arenas of the wavefront
+// wait for them.  Here every LANE keeps its own step count: a lane whose arena was flagged posts the task and
+// sits out lane passes until the task's completion word shows up; the other lanes of the wavefront go on with
+// their next steps, each with its own step's controls.  After a lane pass a wavefront serves one round if the
+// queue holds a full one or a task it has seen waiting GSIM_POOL_AGE times (default 1: anything that is there;
+// waiting for full rounds -- a round costs the same ~40 k cycles with one arena as with GPW -- was measured: a
+// third fewer rounds, 12 % slower, the waiting time is lag), and everything there is when none of its lanes
+// can step.  A wavefront ends when each of its arenas has done its n_steps; the lag a lane collects (one or two
+// lane passes per flagged step) is what the asynchrony costs, and three rules bound it: the lag bound
+// (GSIM_POOL_LAGMAX, below), the follow-up of arenas in lasting contact (GSIM_POOL_STREAK, pool_round) and the
+// last few stragglers going through the wave pass (GSIM_POOL_FEW).  Arithmetic per arena-step: lane_step or
 // arena_step_group, both unchanged -- the order in which arena-steps of DIFFERENT arenas are run has no
-// influence on any value.
+// influence on any value.  DESIGN.md 3.3b has the measurements behind each rule.
 #ifndef GSIM_POOL_AGE
 #define GSIM_POOL_AGE 1
 #endif
 #ifndef GSIM_POOL_BUSYMAX
-#define GSIM_POOL_BUSYMAX 99                                 // 0: a round's worth (GPW); 99: off
+#define GSIM_POOL_BUSYMAX 99                                 // hold the wavefront while this many of its arenas are out (0: GPW); 99: off (measured: C2 -8 %)
 #endif
 #ifndef GSIM_POOL_FEW
 #define GSIM_POOL_FEW 4
