@@ -368,8 +368,8 @@ __device__ __forceinline__ EventLane<N> event_lane(const StepArgs &p, const Grid
 }
 
 // correctOverlap of one re-integrated column (pair: cpp:581-592, wall: cpp:594-623), then the store
-// into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).  Select-based: the
-// square root is taken whether or not the discs overlap.
+// into the grid.  Lanes 0..3 of the group, all active together (DPP exchanges).  The pair rule's square
+// root sits behind a branch that is uniform over those four lanes (GSIM_FIX_BRANCH).
 template <int N, bool SPLITV>
 __device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const GridView<N, SPLITV> &G, Chain &x, int g,
                                                  bool wall_fix) {
@@ -377,11 +377,19 @@ __device__ __forceinline__ void fix_store_column(const EventLane<N> &c, const Gr
     const double po = quad_xor2(x.p);
     const double pij = c.first ? po - x.p : x.p - po;
     const double sq = pij * pij;
-    const double s = sq + quad_xor1(sq);
+    const double s = sq + quad_xor1(sq);                             // the same value on the event's four lanes
+#if GSIM_FIX_BRANCH
+    if (s <= c.lt) {                                                 // overlap > 0 (cpp:584-585): rare after the impact column,
+      const double overlap = c.rsum - sqrt_ieee(s);                  // and the square root is a third of this column's latency
+      const double cc = (c.first ? -c.push11 : c.push11) * overlap;  // -(a*b) == (-a)*b exactly
+      x.p = x.p + cc * pij;                                          // x - c*pij == x + (-(c*pij))
+    }
+#else
     const double overlap = c.rsum - sqrt_ieee(s);
     const double cc = (c.first ? -c.push11 : c.push11) * overlap;    // -(a*b) == (-a)*b exactly
     const double moved = x.p + cc * pij;                             // x - c*pij == x + (-(c*pij))
     x.p = (s <= c.lt) ? moved : x.p;
+#endif
   } else if (c.my_axis && wall_fix) {
     const double overlap = c.positive_wall ? (x.p + c.r_own - c.wall) : (-x.p + c.r_own - c.wall);
     const double cc = 1.1 * overlap;
