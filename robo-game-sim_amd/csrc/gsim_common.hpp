@@ -203,26 +203,40 @@ __device__ __forceinline__ double div_tau(double a, double tau, double inv) {
   return a / tau;
 }
 
+#ifndef GSIM_RK4_FMA_NUM
+#define GSIM_RK4_FMA_NUM 1
+#endif
+#if GSIM_RK4_FMA_NUM
+#define GSIM_RK4_NUM(nc, v, u) __builtin_fma((nc), (v), (u))
+#else
+#define GSIM_RK4_NUM(nc, v, u) ((u) + (nc) * (v))
+#endif
+
 // RK4_player / RK4_puck (src/GameSim.cpp:70-88, 98-116) restricted to one axis.
 //   f(x) = (v, (u - coef*v)/tau): coef = 1 for players (cpp:66-67 with sigma = 0;
 //   1.0*v is exact), 0.2 for the puck (cpp:94-95, whose u is always 0).
 // The position rows of x2..x4 never feed f, so only their velocity rows exist here.
 // cpp:87 combines x + (k1 + k2*2 + k3*2 + k4)*(dt/6); k*2 is exact, so fma(k, 2, acc) rounds
 // exactly once like the reference's multiply-then-add and is bit-identical to it.
+// The numerator u - coef*v is ONE fma here: for a player coef = 1, the product is exact and fma(-1, v, u) = RN(u - v);
+// for the puck u = 0 (always, cpp:188) and fma(-0.2, v, 0) = -RN(0.2*v) = RN(0 - RN(0.2*v)), zeros included
+// (v = +-0 gives +0 both ways).  Callers keep to (coef == 1) or (u == 0).  One dependent operation less per stage
+// on the wave pass' serial chains.
 template <int DM>
 __device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double tau, double inv, double h) {
   const double half = h / 2.0;
+  const double nc = -coef;
   const double k1p = x.v;
-  const double k1v = div_tau<DM>(u - coef * x.v, tau, inv);
+  const double k1v = div_tau<DM>(GSIM_RK4_NUM(nc, x.v, u), tau, inv);
   const double x2v = x.v + k1v * half;
   const double k2p = x2v;
-  const double k2v = div_tau<DM>(u - coef * x2v, tau, inv);
+  const double k2v = div_tau<DM>(GSIM_RK4_NUM(nc, x2v, u), tau, inv);
   const double x3v = x.v + k2v * half;
   const double k3p = x3v;
-  const double k3v = div_tau<DM>(u - coef * x3v, tau, inv);
+  const double k3v = div_tau<DM>(GSIM_RK4_NUM(nc, x3v, u), tau, inv);
   const double x4v = x.v + k3v * h;
   const double k4p = x4v;
-  const double k4v = div_tau<DM>(u - coef * x4v, tau, inv);
+  const double k4v = div_tau<DM>(GSIM_RK4_NUM(nc, x4v, u), tau, inv);
   const double w = h / 6.0;
   Chain r;
   r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;   // cpp:87
