@@ -34,6 +34,9 @@
 #ifndef GSIM_H2_SPLIT_BIG
 #define GSIM_H2_SPLIT_BIG 1        // two-lane hybrid, 6v6/7v7: velocity rows of the grid in global scratch
 #endif
+#ifndef GSIM_FLOAT_BOUND
+#define GSIM_FLOAT_BOUND 1         // lane pass: the watch's per-disc speed bounds from a single-precision square root (rounded up)
+#endif
 #ifndef GSIM_FIX_BRANCH
 #define GSIM_FIX_BRANCH 1          // correctOverlap of a re-integrated column: take the square root only when the discs overlap
 #endif

@@ -137,6 +137,17 @@ __device__ __forceinline__ void rk4_chains(double *__restrict__ p_all, double *_
 #undef GSIM_EACH
 }
 
+// An upper bound of sqrt(x) for the watch's speed bounds, x >= 0 and far below FLT_MAX: single-precision square root
+// (1 ulp) of x rounded to float, the three roundings (< 2^-22 relative together) covered by the factor; the
+// addend covers arguments that round to zero as a float.  Four instructions where the double-precision root is ~30.
+__device__ __forceinline__ double sqrt_upper(double x) {
+#if GSIM_FLOAT_BOUND
+  return (double)__builtin_amdgcn_sqrtf((float)x) * (1.0 + 0x1p-20) + 1.0e-18;
+#else
+  return __builtin_sqrt(x) * (1.0 + 1.0e-12);
+#endif
+}
+
 // All M chains of an arena, at most 10 at a time (more would spill registers at 4v4 and up).
 template <int MODE, int M, int PKC, int C0 = 0>
 __device__ __forceinline__ void rk4_all_chains(double *p, double *v, const double *u, double tau_pl, double inv_pl,
@@ -201,7 +212,7 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
   for (int e = 0; e < E; ++e) {
     const double cx = __builtin_fmax(__builtin_fabs(vel[2 * e]), __builtin_fabs(u[2 * e]));
     const double cy = __builtin_fmax(__builtin_fabs(vel[2 * e + 1]), __builtin_fabs(u[2 * e + 1]));
-    const double se = __builtin_sqrt(__builtin_fma(cx, cx, cy * cy)) * (1.0 + 1.0e-12);
+    const double se = sqrt_upper(__builtin_fma(cx, cx, cy * cy));
     const double lo = __builtin_fmin(s1, se);
     s1 = __builtin_fmax(s1, se);
     s2 = __builtin_fmax(s2, lo);
@@ -340,7 +351,7 @@ __device__ __forceinline__ bool lane_step_split(const StepArgs &p, const double 
   for (int e = 0; e < E; ++e) {
     const double c = __builtin_fmax(__builtin_fabs(vel[e]), __builtin_fabs(u[e]));
     const double cc = c * c;
-    const double se = __builtin_sqrt(cc + quad_xor1(cc)) * (1.0 + 1.0e-12);   // both lanes of the arena: the same sum
+    const double se = sqrt_upper(cc + quad_xor1(cc));       // both lanes of the arena: the same sum
     const double lo = __builtin_fmin(s1, se);
     s1 = __builtin_fmax(s1, se);
     s2 = __builtin_fmax(s2, lo);
