@@ -35,9 +35,10 @@ enum {
   RGS_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
 };
 
-/* Stepper variants (rgs_set_variant).  All give bit-identical results.  AUTO picks the hybrid that
- * suits n and, looking at the event counters every >= 64 steps, falls back to the wave-per-arena
- * kernel while most arenas are in contact. */
+/* Stepper variants (rgs_set_variant).  All give bit-identical results.  AUTO picks the kernel with the
+ * highest measured rate for this team size, batch size, launch length and step length (csrc/auto_rates.h,
+ * generated from a sweep on MI355X) and, looking at the event counters every >= 64 steps, falls back to the
+ * wave-per-arena kernel while most arenas are in contact. */
 enum {
   RGS_VARIANT_AUTO = 0,
   RGS_VARIANT_WAVE = 1,      /* one wavefront owns one arena, grid in LDS */
