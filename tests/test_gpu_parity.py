@@ -673,3 +673,27 @@ def test_every_kernel_instantiation_matches_oracle(rgp, oracle, n):
             assert_same(sim.damage().reshape(4 * n * n, B), ref["damage"], what + " damage")
             assert sim.counters()["resolved"] == ref["stats"]["resolved"], what
             sim.close()
+
+
+@pytest.mark.parametrize("variant", [4, 5], ids=["pool", "apool"])
+@pytest.mark.parametrize("B", [1, 3, 63, 257, 1000])
+def test_pooled_kernels_on_ragged_batches(rgp, oracle, variant, B):
+    """The pooled kernels own 256 arenas per workgroup: batches that leave wavefronts partly or wholly empty, a
+    single arena, launches of one step and of many, and a launch that records trajectories (which switches the
+    asynchronous pool's follow-up and straggler rules off) must all give the oracle's bits."""
+    from robo_game_py import workloads as w
+    n, K, dt = 2, 40, 0.05
+    x0, amp, ph = w.c2_inputs(B, n, seed=500 + B)
+    table = w.circle_controls(amp * 2.0, ph, w.step_times(K, dt))
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=3, n_threads=8, rec_every=8)
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_variant(variant)
+    sim.reset(dt, 3, x0)
+    got = sim.run_table(table[:1], chunk_steps=1)              # one launch of one step
+    got = sim.run_table(table[1:], chunk_steps=K)              # one launch of the other 39
+    assert_same(got, ref["state"], "B=%d variant=%d fused" % (B, variant))
+    assert sim.counters()["resolved"] == ref["stats"]["resolved"]
+    sim.reset(dt, 3, x0)
+    traj = sim.run_table_traj(table, 8)
+    assert_same(traj, ref["traj"], "B=%d variant=%d in-kernel snapshots" % (B, variant))
+    sim.close()
