@@ -104,11 +104,14 @@ struct StepArgs {
   int watch_every;                   // lane pass: overlap watch every 5th column (1 = every column)
   int wall_ends;                     // lane pass: wall watch at column 50 only (monotone-coordinate argument, gsim_lane.hpp)
   // noise > 0 (wave kernel only): w_stdev_ (cpp:30) and the per-arena tape of N(0,1) draws the host
-  // generated with the reference's own engine/distribution (cpp:3,41,66-67); tape[a*tape_len + k].
+  // generated with the reference's own engine/distribution (cpp:3,41,66-67): arena a's draws are
+  // tape[tape_off[a] + k], k < tape_n[a] (arenas whose step overflowed a short tape get a longer one elsewhere
+  // in the buffer, the others keep theirs).
   double sigma;
   const double *tape;
-  int tape_len;
-  int *consumed;                     // [B] draws used by this step (> tape_len: tape too short, redo)
+  const long long *tape_off;         // [B]
+  const int *tape_n;                 // [B]
+  int *consumed;                     // [B] draws used by this step (> tape_n[a]: tape too short, redo)
   // trajectory snapshots inside a fused launch: after step k (1-based, counted within the launch) with
   // k % traj_every == 0 the state of every arena is copied to traj[(k/traj_every - 1)][S][B]
   double *traj;

@@ -488,8 +488,8 @@ __device__ bool arena_step_group(const StepArgs &p, const double *__restrict__ c
   if (!(TAS < p.win && TBS < p.win)) return false;           // undecided(), cpp:57-60,121
   const double t0 = gld_at<COH>(p.tcur, a, p.n_tcur);
   const double dt = p.dt, dt_col = p.dt_col;
-  const double *tape = NOISE ? p.tape + a * (long long)p.tape_len : nullptr;
-  const int tape_last = NOISE ? p.tape_len - 8 : 0;         // last legal start of an 8-draw record
+  const double *tape = NOISE ? p.tape + p.tape_off[a] : nullptr;
+  const int tape_last = NOISE ? p.tape_n[a] - 8 : 0;        // last legal start of an 8-draw record
   int cur = 0;                                              // draws consumed so far (group-uniform)
   const bool stamp = GSIM_STAMPS && p.stamps && gbase == 0;               // diagnostic: group 0 times its phases
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;

@@ -105,6 +105,12 @@ struct rgs_sim {
   std::vector<std::normal_distribution<double>> wdist;
   std::vector<double> tape_host;
   std::vector<int> consumed_host;
+  std::vector<long long> tapeoff_host;                         // per-arena tape start / length (noise_step)
+  std::vector<int> tapen_host;
+  std::vector<std::default_random_engine> snap_eng;            // generator state after an event-free step's draws
+  std::vector<std::normal_distribution<double>> snap_dist;
+  long long *tapeoff_dev = nullptr;
+  int *tapen_dev = nullptr;
   double *tape_dev = nullptr, *bak_state = nullptr, *bak_tcur = nullptr, *bak_damage = nullptr;
   int *consumed_dev = nullptr;
   unsigned long long *bak_counters = nullptr;
@@ -284,58 +290,82 @@ void parallel_arenas(long long n, F fn) {
   for (auto &th : pool) th.join();
 }
 
-// One step with w_stdev_ != 0.  The host draws a tape of N(0,1) values per arena from COPIES of the
-// arena's generator, the wave kernel consumes them in the reference's call order and reports how many
-// it used, and the real generators are then advanced by exactly that many draws.  A step whose events
-// need more draws than the first, short tape holds is redone from a backup with the worst-case length.
+// One step with w_stdev_ != 0.  The host draws a tape of N(0,1) values per arena from COPIES of the arena's
+// generator, the wave kernel consumes them in the reference's call order and reports how many it used, and the
+// real generators are then set to the state after exactly that many draws.  The first tape holds the draws of
+// an event-free step plus one event; an arena whose step needs more gets a longer tape (6 events, then the
+// 49-event worst case) appended to the buffer and the step is redone from a backup -- for everybody on the
+// device (cheap), but only the overflowing arenas' tapes are drawn again (the host's draws are what this path
+// costs).  The generator state after the event-free count (what nearly every arena-step consumes) is kept from
+// the tape's own generation, so the common case draws each value once.
 int noise_step(rgs_sim *s, StepArgs a) {
   const long long B = s->B;
   const int P = s->P;
   const int base_draws = 8 * kGrid * P;
   const int per_event = 8 * 2 * (kGrid + 3);
-  const int lens[2] = {base_draws + 6 * per_event, base_draws + (kLoopCap - 1) * per_event};
+  const int lens[3] = {base_draws + per_event, base_draws + 6 * per_event, base_draws + (kLoopCap - 1) * per_event};
   HIP_TRY(hipMemcpyAsync(s->bak_state, s->state, sizeof(double) * s->S * B, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->bak_tcur, s->tcur, sizeof(double) * B, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->bak_damage, s->damage, sizeof(double) * P * P * B, hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->bak_counters, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToDevice, s->stream));
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  s->tapeoff_host.resize(B); s->tapen_host.resize(B);
+  s->snap_eng.resize(B); s->snap_dist.resize(B, std::normal_distribution<double>(0.0, 1.0));
+  s->consumed_host.resize(B);
+  std::vector<long long> todo(B);                              // arenas whose tape is (re)drawn in this attempt
+  for (long long ar = 0; ar < B; ++ar) todo[ar] = ar;
+  size_t used = 0;                                             // doubles of the buffer in use
+  for (int attempt = 0; attempt < 3; ++attempt) {
     const int T = lens[attempt];
-    const size_t need = (size_t)T * (size_t)B;
-    if (need > s->tape_cap) {
-      HIP_TRY(hipStreamSynchronize(s->stream));
-      dev_free(s, s->tape_dev);
-      s->tape_dev = nullptr;
-      HIP_TRY(dev_alloc(s, &s->tape_dev, sizeof(double) * need, "tape_dev"));
-      s->tape_cap = need;
-    }
-    s->tape_host.resize(need);
-    parallel_arenas(B, [&](long long lo, long long hi) {
-      for (long long ar = lo; ar < hi; ++ar) {
-        std::default_random_engine e = s->reng[ar];            // copies: the originals advance later
+    const size_t first = used;
+    used += (size_t)T * todo.size();
+    s->tape_host.resize(used);
+    parallel_arenas((long long)todo.size(), [&](long long lo, long long hi) {
+      for (long long q = lo; q < hi; ++q) {
+        const long long ar = todo[q];
+        std::default_random_engine e = s->reng[ar];            // copies: the originals are set at the end
         std::normal_distribution<double> d = s->wdist[ar];
-        double *t = s->tape_host.data() + (size_t)ar * T;
-        for (int k = 0; k < T; ++k) t[k] = d(e);               // w_dist_(reng_), src/GameSim.cpp:66-67
+        double *t = s->tape_host.data() + first + (size_t)q * T;
+        for (int k = 0; k < base_draws; ++k) t[k] = d(e);      // w_dist_(reng_), src/GameSim.cpp:66-67
+        if (attempt == 0) { s->snap_eng[ar] = e; s->snap_dist[ar] = d; }   // the state after an event-free step
+        for (int k = base_draws; k < T; ++k) t[k] = d(e);
+        s->tapeoff_host[ar] = (long long)(first + (size_t)q * T);
+        s->tapen_host[ar] = T;
       }
     });
-    HIP_TRY(hipMemcpyAsync(s->tape_dev, s->tape_host.data(), sizeof(double) * need, hipMemcpyHostToDevice, s->stream));
-    a.tape = s->tape_dev; a.tape_len = T; a.sigma = s->sigma; a.consumed = s->consumed_dev;
+    if (used > s->tape_cap) {                                  // grow: everything drawn so far is re-sent (rare)
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      dev_free(s, s->tape_dev);
+      s->tape_dev = nullptr; s->tape_cap = 0;
+      HIP_TRY(dev_alloc(s, &s->tape_dev, sizeof(double) * used, "tape_dev"));
+      s->tape_cap = used;
+      HIP_TRY(hipMemcpyAsync(s->tape_dev, s->tape_host.data(), sizeof(double) * used, hipMemcpyHostToDevice, s->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(s->tape_dev + first, s->tape_host.data() + first, sizeof(double) * (used - first),
+                             hipMemcpyHostToDevice, s->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(s->tapeoff_dev, s->tapeoff_host.data(), sizeof(long long) * B, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->tapen_dev, s->tapen_host.data(), sizeof(int) * B, hipMemcpyHostToDevice, s->stream));
+    a.tape = s->tape_dev; a.tape_off = s->tapeoff_dev; a.tape_n = s->tapen_dev; a.sigma = s->sigma; a.consumed = s->consumed_dev;
     a.n_steps = 1; a.ctl_stride = 0;
     HIP_TRY(hipMemsetAsync(s->consumed_dev, 0, sizeof(int) * B, s->stream));   // decided arenas draw nothing
     int rc = launch_kind(s, a, LAUNCH_WAVE_NOISE, 0);
     if (rc != RGS_OK) return rc;
-    s->consumed_host.resize(B);
     HIP_TRY(hipMemcpyAsync(s->consumed_host.data(), s->consumed_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    bool overflow = false;
-    for (long long ar = 0; ar < B; ++ar) overflow |= s->consumed_host[ar] > T;
-    if (!overflow) {
+    todo.clear();
+    for (long long ar = 0; ar < B; ++ar)
+      if (s->consumed_host[ar] > s->tapen_host[ar]) todo.push_back(ar);
+    if (todo.empty()) {
       parallel_arenas(B, [&](long long lo, long long hi) {
-        for (long long ar = lo; ar < hi; ++ar)
-          for (int k = 0; k < s->consumed_host[ar]; ++k) (void)s->wdist[ar](s->reng[ar]);
+        for (long long ar = lo; ar < hi; ++ar) {
+          const int c = s->consumed_host[ar];
+          if (c == base_draws) { s->reng[ar] = s->snap_eng[ar]; s->wdist[ar] = s->snap_dist[ar]; }
+          else for (int k = 0; k < c; ++k) (void)s->wdist[ar](s->reng[ar]);
+        }
       });
       return RGS_OK;
     }
-    if (attempt == 1) return fail(RGS_ERR_HIP, "noise_step: worst-case tape still too short (internal error)");
+    if (attempt == 2) return fail(RGS_ERR_HIP, "noise_step: worst-case tape still too short (internal error)");
     HIP_TRY(hipMemcpyAsync(s->state, s->bak_state, sizeof(double) * s->S * B, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->tcur, s->bak_tcur, sizeof(double) * B, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->damage, s->bak_damage, sizeof(double) * P * P * B, hipMemcpyDeviceToDevice, s->stream));
@@ -386,7 +416,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.n_state = (long long)s->S * s->B; a.n_tcur = s->B; a.n_damage = (long long)s->P * s->P * s->B;
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
-  a.sigma = 0.0; a.tape = nullptr; a.tape_len = 0; a.consumed = nullptr; a.vgrid = nullptr;
+  a.sigma = 0.0; a.tape = nullptr; a.tape_off = nullptr; a.tape_n = nullptr; a.consumed = nullptr; a.vgrid = nullptr;
   a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
@@ -553,7 +583,7 @@ int rgs_destroy(rgs_sim *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
-  dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
+  dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->tapeoff_dev); dev_free(s, s->tapen_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -573,6 +603,8 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
       HIP_TRY(dev_alloc(s, &s->bak_tcur, sizeof(double) * s->B, "bak_tcur"));
       HIP_TRY(dev_alloc(s, &s->bak_damage, sizeof(double) * s->P * s->P * s->B, "bak_damage"));
       HIP_TRY(dev_alloc(s, &s->consumed_dev, sizeof(int) * s->B, "consumed_dev"));
+      HIP_TRY(dev_alloc(s, &s->tapeoff_dev, sizeof(long long) * s->B, "tapeoff_dev"));
+      HIP_TRY(dev_alloc(s, &s->tapen_dev, sizeof(int) * s->B, "tapen_dev"));
       HIP_TRY(dev_alloc(s, &s->bak_counters, sizeof(unsigned long long) * CNT_N, "bak_counters"));
     }
     s->reng.resize(s->B);
