@@ -141,6 +141,7 @@ hipError_t dev_alloc(rgs_sim *s, T **out, size_t bytes, const char *name) {
   if (e != hipSuccess) return e;
   if (g) {
     e = hipMemset(base, 0xA5, bytes + 2 * g);
+    if (e == hipSuccess) e = hipDeviceSynchronize();          // the fill runs on the null stream; the handle's stream does not wait for it
     if (e != hipSuccess) { (void)hipFree(base); return e; }
   }
   s->guards.push_back({name, base, bytes});
