@@ -34,6 +34,9 @@
 #ifndef GSIM_H2_SPLIT_BIG
 #define GSIM_H2_SPLIT_BIG 1        // two-lane hybrid, 6v6/7v7: velocity rows of the grid in global scratch
 #endif
+#ifndef GSIM_PAIR_BOUNDS
+#define GSIM_PAIR_BOUNDS 1         // one-lane lane pass at 3v3: the pair watch's radius widened per pair by its own two discs' speed bounds
+#endif
 #ifndef GSIM_FLOAT_BOUND
 #define GSIM_FLOAT_BOUND 1         // lane pass: the watch's per-disc speed bounds from a single-precision square root (rounded up)
 #endif
