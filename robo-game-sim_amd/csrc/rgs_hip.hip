@@ -454,10 +454,11 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   if (s->variant == RGS_VARIANT_AUTO) s->window_steps += n_steps;
   // Which kernel: estimated arena-steps/s (x1e6) from the rates in auto_rates.h, a header GENERATED from a sweep on
   // MI355X (tools/sweep.py -> profiles/r02/sweep_auto.json -> tools/rates_to_header.py); nothing measured is typed in
-  // here.  The hybrids are measured at 32 768 and 65 536 arenas (linear in between and below, flat above: the one-lane
-  // kernels need 65 536 arenas to put a wavefront on every SIMD, the two-lane one 32 768); the wave-per-arena kernel
-  // spreads even a few hundred arenas over the whole chip and is modelled as B / (t0 + B / saturated rate) through its
-  // 1 024- and 65 536-arena points.  Launches of few steps are tail-dominated and have their own table ("short"); the
+  // here.  The hybrids are measured at 32 768, 65 536 and 131 072 arenas (linear in between and below the first, flat
+  // above the last: the one-lane kernels need 65 536 arenas to put a wavefront on every SIMD, the two-lane one 32 768,
+  // and beyond that the workgroups run in successive waves over the CUs); the wave-per-arena kernel spreads even a few
+  // hundred arenas over the whole chip and is modelled as B / (t0 + B / saturated rate) through its 1 024- and
+  // 131 072-arena points.  Launches of few steps are tail-dominated and have their own table ("short"); the
   // share of arena-steps with events grows with the step length, so the table is measured at dt = 0.01 and 0.05 and the
   // nearer one (in ratio) is used.
   // The pooled hybrids' workgroups (256 arenas, ~140 KB of LDS: one per CU) are self-contained; with more of them than
@@ -469,15 +470,17 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   const double Bd = (double)s->B;
   auto hybrid_rate = [&](int kern) {
     const double r32 = kAutoRate[dtc][regime][kern][0][s->n], r65 = kAutoRate[dtc][regime][kern][1][s->n];
+    const double r131 = kAutoRate[dtc][regime][kern][2][s->n];
     if (Bd <= 32768.0) return r32 * Bd / 32768.0;
-    if (Bd >= 65536.0) return r65;
+    if (Bd >= 131072.0) return r131;
+    if (Bd >= 65536.0) return r65 + (r131 - r65) * (Bd - 65536.0) / 65536.0;
     return r32 + (r65 - r32) * (Bd - 32768.0) / 32768.0;
   };
   const double est_one = hybrid_rate(1), est_two = hybrid_rate(2);
   const double est_pool = hybrid_rate(3), est_apool = hybrid_rate(4);
   double est_wave = 0.0;
   {
-    const double sat = kAutoRate[dtc][regime][0][1][s->n], r1k = kAutoWave1k[dtc][regime][s->n];
+    const double sat = kAutoRate[dtc][regime][0][2][s->n], r1k = kAutoWave1k[dtc][regime][s->n];
     if (sat > 0.0 && r1k > 0.0) {
       const double t0 = 1024.0 / r1k - 1024.0 / sat;           // microseconds
       est_wave = Bd / ((t0 > 0.0 ? t0 : 0.0) + Bd / sat);

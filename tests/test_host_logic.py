@@ -162,7 +162,7 @@ def test_auto_rate_header_is_what_the_committed_sweep_generates(tmp_path):
         assert open(hdr).read() == before, "auto_rates.h is stale: re-run tools/rates_to_header.py and rebuild"
     finally:
         open(hdr, "w").write(before)
-    assert "kAutoRate[kAutoDts][2][5][2][8]" in before and "kAutoDt[kAutoDts] = {0.01, 0.05}" in before
+    assert "kAutoRate[kAutoDts][2][5][3][8]" in before and "kAutoDt[kAutoDts] = {0.01, 0.05}" in before
 
 
 def test_bench_dt_override_keeps_the_presets():
