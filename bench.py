@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 wave-per-arena, 2 hybrid, 3 two-lane hybrid, 4 pooled hybrid, 5 asynchronous pooled hybrid")
     ap.add_argument("--cpu-sample-arenas", type=int, default=2048)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg (a 1-GPU box's CPU share)")
+    ap.add_argument("--cpu-seconds", type=float, default=2.5, help="target duration of each cpu_baseline leg (all threads, "
+                    "one thread, reference-faithful RNG); never below 0.5 s of measured work")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--no-streamed", action="store_true", help="c5: skip the host-streamed leg (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
@@ -110,6 +112,68 @@ def self_launch(n_ranks):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(orc, w, args, n, x0, amp, ph, cores):
+    """The CPU oracle timed on this host on a bounded sample of the SAME workload (same generator, same parameters;
+    SURVEY 8d / BASELINE.md section 3): independent of --steps, every leg runs for >= 0.5 s.  The sample is the first
+    arenas of this rank for max(W+K, 200) steps from reset, controls computed on the host (numpy) -- what the CPU
+    computes is the workload, not the GPU's table, so its values need not be the device's to the last ulp (parity
+    above uses the device's own table).  Legs: all `cores` threads with the dead RNG draws elided; ONE thread; all
+    threads with the reference's 2 normal draws per f_player call (src/GameSim.cpp:66-67).  Each leg's arena count is
+    grown from a short calibration run until the leg runs for about `args.cpu_seconds`."""
+    P = 2 * n
+    steps = min(max(args.warmup + args.steps, 200), 1010)
+    times = w.step_times(steps, args.dt)
+    cap = min(8192, x0.shape[1])
+
+    def leg(arenas, threads, draw_always):
+        arenas = max(1, min(cap, int(arenas)))
+        tab = w.circle_controls(amp[:, :arenas], ph[:, :arenas], times)
+        if args.config == "c4":
+            tab[0] = 0.0                                           # py/MonteCarlo.py:33
+        xs = np.ascontiguousarray(x0[:, :arenas])
+        t1 = time.perf_counter()
+        orc.batch_run(n, xs, tab, steps, dt=args.dt, winning_score=args.win, n_threads=threads, draw_always=draw_always)
+        el = time.perf_counter() - t1
+        return arenas, el, arenas * steps / el
+
+    out = {}
+    total = 0.0
+    for name, threads, draw in (("all", cores, False), ("one", 1, False), ("faithful", cores, True)):
+        arenas, el, rate = leg(8 * threads, threads, draw)         # calibration (also starts the thread pool)
+        total += el
+        for _ in range(3):                                         # grow the sample until it runs for about cpu_seconds
+            if el >= 0.6 * args.cpu_seconds or arenas >= cap:
+                break
+            arenas, el, rate = leg(max(arenas + 1, arenas * args.cpu_seconds / max(el, 1e-4)), threads, draw)
+            total += el
+        out[name] = (arenas, el, rate)
+    a_all, s_all, r_all = out["all"]
+    a_one, s_one, r_one = out["one"]
+    a_f, s_f, r_f = out["faithful"]
+    return {"value": round(r_all, 1), "unit": "arena-steps/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_string(), "host_cpus": os.cpu_count(),
+            "sample": "%d arenas x %d steps of this workload from reset (host-computed controls of the same generator), "
+                      "oracle/gamesim_oracle.cpp (g++ -O2 -ffp-contract=off, OpenMP over arenas), dead RNG draws elided"
+                      % (a_all, steps),
+            "sample_seconds": round(s_all, 3),
+            "one_thread_value": round(r_one, 1), "one_thread_sample": "%d arenas x %d steps" % (a_one, steps),
+            "one_thread_seconds": round(s_one, 3),
+            "reference_faithful_rng_value": round(r_f, 1),
+            "reference_faithful_rng_sample": "%d arenas x %d steps, %d threads, 2 normal draws per f_player call as "
+                                             "src/GameSim.cpp:66-67" % (a_f, steps, cores),
+            "reference_faithful_rng_seconds": round(s_f, 3), "total_cpu_leg_seconds": round(total, 2)}
 
 
 def main():
@@ -324,21 +388,14 @@ def main():
     fp64_model = {"flops_per_arena_step": model_flops_per_arena_step(n), "achieved": round(model_tflops, 4),
                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(model_tflops / FP64_VECTOR_PEAK_TFLOPS, 5)}
 
-    # ---- CPU baseline + parity of the sampled arenas (rank 0, every N) ------------------------
+    # ---- parity of the sampled arenas + CPU baseline (rank 0, every N) ------------------------
     cpu = None
     parity = None
     if rank == 0 and check:
         from oracle import oracle as orc
         nc = cs0 + cs1
         cores = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
-        t1 = time.perf_counter()
         ref = orc.batch_run(n, x0s, sub, W + K, dt=DT, winning_score=WIN, n_threads=cores)
-        cpu_s = time.perf_counter() - t1
-        cf = max(1, nc // 4)
-        t1 = time.perf_counter()
-        orc.batch_run(n, np.ascontiguousarray(x0s[:, :cf]), np.ascontiguousarray(sub[:, :, :, :cf]), W + K, dt=DT,
-                      winning_score=WIN, n_threads=cores, draw_always=True)
-        cpu_faithful_s = time.perf_counter() - t1
         delta = float(np.max(np.abs(got - ref["state"])))
         parity = {"arenas_checked": nc, "steps": W + K, "max_abs_delta_vs_oracle": delta,
                   "scores_equal": bool(np.array_equal(got[:2], ref["state"][:2])),
@@ -351,12 +408,7 @@ def main():
                                winning_score=WIN, n_threads=cores)
             parity["host_streamed_bit_identical"] = bool(np.array_equal(streamed_state, rs["state"]))
             parity["host_streamed_arenas_x_steps"] = "%d x %d" % (cs0, ks)
-        cpu = {"value": round(nc * (W + K) / cpu_s, 1), "unit": "arena-steps/s", "cores": cores, "kind": "port",
-               "sample": "%d arenas x %d steps of this workload, oracle/gamesim_oracle.cpp (g++ -O2 "
-                         "-ffp-contract=off, OpenMP over arenas), dead RNG draws elided" % (nc, W + K),
-               "reference_faithful_rng_value": round(cf * (W + K) / cpu_faithful_s, 1),
-               "reference_faithful_rng_sample": "%d arenas x %d steps, 2 normal draws per f_player call as "
-                                                "src/GameSim.cpp:66-67" % (cf, W + K)}
+        cpu = cpu_baseline(orc, w, args, n, x0, amp, ph, cores)
 
     if rank == 0:
         controls = ("per-run seeds %d..%d drive the control generator, x0_ball=(-1,0,0,0), 1 zero-command step + %d "

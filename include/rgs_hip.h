@@ -140,24 +140,31 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * out[0] events resolved, [1] steps ended by the 50-iteration cap (include/GameSim.h:7),
  * [2] base index past the grid (reference: out-of-bounds write; clamped here), [3] puck events
  * skipped after a goal (src/GameSim.cpp:230-231), [4] arena-steps whose first scan found an
- * event, [5] arena-steps the hybrid's lane pass handed to the wave pass, [6] reserved, [7] 1 if
- * RGS_VARIANT_AUTO currently prefers the wave-per-arena kernel (sustained-contact regime), else 0. */
+ * event, [5] arena-steps the hybrid's lane pass handed to the wave pass, [6] bounded waits of the pooled
+ * kernels that ran out (a protocol error: never seen; non-zero poisons the handle -- this call and every
+ * synchronising call (rgs_sync, rgs_get_*, rgs_step, rgs_step_roundtrip, rgs_device_download) return
+ * RGS_ERR_HIP until the next rgs_reset), [7] 1 if RGS_VARIANT_AUTO currently prefers the wave-per-arena
+ * kernel (sustained-contact regime), else 0. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
 
 /* Diagnostic in-kernel stamps (s_memtime) of the hybrid kernels; only in a library built with
  * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable: bit 0 = stamps on
- * for later launches, bit 1 = clear the totals first.  out17 (may be NULL) receives 17 values since the
+ * for later launches, bit 1 = clear the totals first.  out (may be NULL) receives up to 17 values since the
  * last reset/clear.  Summed over waves: lane-pass cycles, wave-pass cycles, wave-pass rounds,
  * whole-kernel cycles; for lane group 0 of every wave pass: fill, first-scan, event-loop, commit cycles
  * and the arena count; maxima over waves: whole-kernel cycles, wave-pass cycles, rounds, and the longest
  * single event loop; then, summed over group 0's carried-out events: cycles from the pop to the start of
  * the carry-out, of the carry-out, of the re-scan chunks, and the event count. */
-int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out17);
+int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out, int capacity);   /* writes min(capacity, 17) values */
 
 /* Debug aid (GPU AddressSanitizer is not available here): with RGS_DEBUG_GUARD_BYTES=<n> in the environment every
  * device buffer of a handle carries n guard bytes on both sides; this call returns RGS_ERR_HIP and names the first
  * buffer whose guard zone was overwritten.  Without the variable it is a no-op returning RGS_OK. */
 int rgs_debug_check_guards(rgs_sim *sim);
+
+/* Debug / test aid: sets the pooled kernels' timeout counter as a failed launch would, so that callers can exercise
+ * the sticky error (rgs_get_counters [6]). */
+int rgs_debug_inject_pool_timeout(rgs_sim *sim);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
 

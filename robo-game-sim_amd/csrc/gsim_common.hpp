@@ -46,6 +46,9 @@
 #ifndef GSIM_H2_SPLIT_4
 #define GSIM_H2_SPLIT_4 1          // the same at 4v4
 #endif
+#ifndef GSIM_H2_SPLIT_5
+#define GSIM_H2_SPLIT_5 0          // diagnostic: the split grid at 5v5 too (the instantiation that once gave wrong results)
+#endif
 #ifndef GSIM_STAMPS
 #define GSIM_STAMPS 0
 #endif

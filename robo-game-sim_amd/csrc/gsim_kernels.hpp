@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
       } else if (lent != 0) {
         break;                                               // nothing of its own: one round lent per step
       }
-      if (pool_round<N, FAST, false>(p, Q, G, wg_a0, lane, grp, lg)) { lent = 1; n_rounds++; }
+      if (pool_round<N, FAST, false>(p, Q, G, wg_a0, lane, grp, lg)) { lent = 1; n_rounds++; waits = 0; }
       else if (n == 0) break;
       else {                                                 // its remaining tasks are running on a sibling: at most one round's time
         __builtin_amdgcn_s_sleep(4);
@@ -320,14 +320,18 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
   }
   // this wavefront's arenas are done; keep serving its siblings until all four are (they are resident: bounded)
   if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (A timeout here only ends this wavefront's help -- its own arenas are complete -- so it is not an error; a sibling
+  // that is really stuck reports its own timeout.  The budget restarts with every served round and finished sibling.)
+  unsigned seen_done = 0u;
   for (int waits = 0;;) {
-    if (pool_round<N, FAST, false>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; continue; }
+    if (pool_round<N, FAST, false>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; waits = 0; continue; }
     unsigned done = 0u;
     if (lane == 0) done = lds_ld(&Q->done);
     done = (unsigned)__shfl((int)done, 0);
     if (done >= (unsigned)kPoolWaves) break;
+    if (done != seen_done) { seen_done = done; waits = 0; }
     __builtin_amdgcn_s_sleep(8);
-    if (++waits > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
+    if (++waits > kPoolSpinLimit) break;
   }
   if (GSIM_STAMPS && p.stamps && lane == 0) {
     const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
@@ -465,20 +469,27 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
       if (__ballot(busy && (int)(lds_ld(&Q->fin[threadIdx.x]) & 0x7FFFFFFFu) > kl) == 0ull) {
         __builtin_amdgcn_s_sleep(4);
         if (++waits > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
+      } else {
+        waits = 0;                                           // a completion came in: the bound measures ONE stall
       }
+    } else {
+      waits = 0;                                             // a lane pass, a posted task or a served round is progress
     }
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
   }
   // this wavefront's arenas are done; keep serving its siblings until all four are (they are resident: bounded)
   if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (as in k_step_pool: a timeout here only ends this wavefront's help and is not an error)
+  unsigned seen_done = 0u;
   for (int spins = 0;;) {
-    if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; continue; }
+    if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; spins = 0; continue; }
     unsigned done = 0u;
     if (lane == 0) done = lds_ld(&Q->done);
     done = (unsigned)__shfl((int)done, 0);
     if (done >= (unsigned)kPoolWaves) break;
+    if (done != seen_done) { seen_done = done; spins = 0; }
     __builtin_amdgcn_s_sleep(8);
-    if (++spins > kPoolSpinLimit) { if (lane == 0) atomicAdd(&p.counters[CNT_POOL_TIMEOUT], 1ull); break; }
+    if (++spins > kPoolSpinLimit) break;
   }
   if (GSIM_STAMPS && p.stamps && lane == 0) {
     const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_begin;
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
 // 5 % with it.
 template <int N>
 struct Hybrid2Split {
-  static constexpr bool value = (GSIM_H2_SPLIT_BIG && N >= 6) || (GSIM_H2_SPLIT_4 && N == 4);
+  static constexpr bool value = (GSIM_H2_SPLIT_BIG && N >= 6) || (GSIM_H2_SPLIT_4 && N == 4) || (GSIM_H2_SPLIT_5 && N == 5);
   static constexpr int LDS_KB = GSIM_H2_LDS_KB;
 };
 

@@ -119,6 +119,11 @@ struct rgs_sim {
   size_t vgrid_cap = 0;
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
   int n_cus = 256;                 // hipDeviceProp_t::multiProcessorCount
+  // Pooled kernels report a bounded wait that ran out in counters[CNT_POOL_TIMEOUT]: arenas may then be short of
+  // their steps.  The error is sticky: every synchronising call checks it (finish()) and fails until the next reset.
+  bool pooled_in_flight = false;   // a pooled launch has been queued since the counters were last looked at
+  bool poisoned = false;
+  unsigned long long *counters_pin = nullptr;   // page-locked mirror of the CNT_N counters
 };
 
 namespace {
@@ -129,7 +134,8 @@ namespace {
 // reports the first buffer whose guard zone was written, and out-of-bounds READS land in mapped memory
 // instead of faulting, which tells an over-read from an over-write.  Off (n = 0) in normal use.
 size_t guard_bytes() {
-  static const size_t g = [] { const char *e = std::getenv("RGS_DEBUG_GUARD_BYTES"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+  // rounded up to a multiple of 256 so the guarded buffers keep hipMalloc's alignment (same coalescing as unguarded)
+  static const size_t g = [] { const char *e = std::getenv("RGS_DEBUG_GUARD_BYTES"); const size_t v = e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; return (v + 255) / 256 * 256; }();
   return g;
 }
 
@@ -159,6 +165,24 @@ void dev_free(rgs_sim *s, T *&ptr) {
   (void)hipFree(base);
   ptr = nullptr;
 }
+
+const char *kPoolTimeoutText = "pooled stepping kernel: a bounded wait timed out (internal protocol error); the arenas' state is invalid until the next reset";
+
+// Waits for the handle's stream.  If a pooled kernel has run since the last look, the counters come along (one 64-byte
+// copy into page-locked memory) and a protocol timeout poisons the handle: this call and every later synchronising call
+// fail until rgs_reset.
+int finish(rgs_sim *s) {
+  if (s->pooled_in_flight && s->counters_pin)
+    HIP_TRY(hipMemcpyAsync(s->counters_pin, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->pooled_in_flight && s->counters_pin) {
+    s->pooled_in_flight = false;
+    if (s->counters_pin[CNT_POOL_TIMEOUT] != 0) s->poisoned = true;
+  }
+  if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
+  return RGS_OK;
+}
+#define RGS_TRY(expr) do { int rc_ = (expr); if (rc_ != RGS_OK) return rc_; } while (0)
 
 // div_tau<true>'s preconditions on the divisor (gsim_common.hpp): normal, moderate exponent,
 // significand not ending in a run of ones.
@@ -419,6 +443,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamp_out = s->counters + CNT_N;
   a.sigma = 0.0; a.tape = nullptr; a.tape_off = nullptr; a.tape_n = nullptr; a.consumed = nullptr; a.vgrid = nullptr;
   a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
+  if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
       a.ctl = ctl_dev + (long long)k * stride;
@@ -444,6 +469,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     unsigned long long c[CNT_N];
     HIP_TRY(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (c[CNT_POOL_TIMEOUT] != 0) { s->poisoned = true; return fail(RGS_ERR_HIP, kPoolTimeoutText); }
     const unsigned long long resolved = c[CNT_RESOLVED];     // counted alike by every kernel
     const double per_step = (double)(resolved - s->seen_busy) / ((double)s->window_steps * (double)s->B);
     if (!s->auto_wave && per_step > 3.0) s->auto_wave = true;
@@ -512,8 +538,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.vgrid = s->vgrid;
     return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
   }
-  if (variant == RGS_VARIANT_POOL && n_steps < (1 << 26)) return launch_kind(s, a, LAUNCH_POOL, div_mode);
-  if (variant == RGS_VARIANT_APOOL && n_steps < (1 << 26)) return launch_kind(s, a, LAUNCH_APOOL, div_mode);
+  if (variant == RGS_VARIANT_POOL && n_steps < (1 << 26)) { s->pooled_in_flight = true; return launch_kind(s, a, LAUNCH_POOL, div_mode); }
+  if (variant == RGS_VARIANT_APOOL && n_steps < (1 << 26)) { s->pooled_in_flight = true; return launch_kind(s, a, LAUNCH_APOOL, div_mode); }
   if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
   return launch_kind(s, a, LAUNCH_WAVE, !fast ? 0 : (s->one_step_ok ? 3 : 1));
 
@@ -569,6 +595,7 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   if (e == hipSuccess) e = dev_alloc(s, &s->ctl, sizeof(double) * s->P * 2 * s->B, "ctl");
   if (e == hipSuccess) e = dev_alloc(s, &s->counters, sizeof(unsigned long long) * (CNT_N + STAMP_N), "counters");
   if (e == hipSuccess) e = dev_alloc(s, &s->flags, (size_t)s->B, "flags");
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->counters_pin, sizeof(unsigned long long) * CNT_N, hipHostMallocDefault);
   if (e != hipSuccess) {
     std::string m = std::string("rgs_create: ") + hipGetErrorString(e);
     rgs_destroy(s);
@@ -588,6 +615,7 @@ int rgs_destroy(rgs_sim *s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
   dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->tapeoff_dev); dev_free(s, s->tapen_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
+  if (s->counters_pin) hipHostFree(s->counters_pin);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -616,6 +644,7 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
     for (long long ar = 0; ar < s->B; ++ar) s->reng[ar] = std::default_random_engine(seed + (int)ar);   // cpp:41
   }
   s->sigma = noise;
+  s->poisoned = false; s->pooled_in_flight = false;
   s->auto_wave = false; s->window_steps = 0; s->seen_busy = 0;
   s->one_step_ok = s->one_step_enabled && one_step_certified(tau_player) && one_step_certified(tau_puck);
   s->dt = dt;
@@ -633,7 +662,7 @@ int rgs_step(rgs_sim *s, const double *controls_host) {
   HIP_TRY(hipMemcpyAsync(s->ctl, controls_host, sizeof(double) * s->P * 2 * s->B, hipMemcpyHostToDevice, s->stream));
   int rc = launch_steps(s, s->ctl, 0, 1);
   if (rc != RGS_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));      // controls_host may be reused by the caller
+  RGS_TRY(finish(s));      // controls_host may be reused by the caller
   return RGS_OK;
 }
 
@@ -675,7 +704,7 @@ int rgs_step_device_record(rgs_sim *s, const double *controls_dev, int64_t step_
 int rgs_sync(rgs_sim *s) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_sync: null handle");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -683,7 +712,7 @@ int rgs_get_state(rgs_sim *s, double *out) {
   if (!s || !out) return fail(RGS_ERR_ARG, "rgs_get_state: null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out, s->state, sizeof(double) * s->S * s->B, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -695,7 +724,7 @@ int rgs_undecided(rgs_sim *s, uint8_t *out) {
                      (double)s->win, s->flags);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, s->flags, (size_t)s->B, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -703,7 +732,7 @@ int rgs_get_damage(rgs_sim *s, double *out) {
   if (!s || !out) return fail(RGS_ERR_ARG, "rgs_get_damage: null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out, s->damage, sizeof(double) * s->P * s->P * s->B, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -711,7 +740,7 @@ int rgs_get_time(rgs_sim *s, double *out) {
   if (!s || !out) return fail(RGS_ERR_ARG, "rgs_get_time: null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out, s->tcur, sizeof(double) * s->B, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -779,7 +808,7 @@ int rgs_device_download(rgs_sim *s, double *dst, const double *src, int64_t n) {
   if (!s || !dst || !src || n < 0) return fail(RGS_ERR_ARG, "rgs_device_download: bad argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -805,7 +834,7 @@ int rgs_step_roundtrip(rgs_sim *s, const double *controls_host, double *state_ho
   int rc = launch_steps(s, s->ctl, 0, 1);
   if (rc != RGS_OK) return rc;
   HIP_TRY(hipMemcpyAsync(state_host, s->state, sizeof(double) * s->S * s->B, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  RGS_TRY(finish(s));
   return RGS_OK;
 }
 
@@ -830,20 +859,23 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(out8, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (out8[6] != 0) return fail(RGS_ERR_HIP, "pooled stepping kernel: a bounded wait timed out (internal protocol error); results are invalid");
+  s->pooled_in_flight = false;
+  if (out8[6] != 0) s->poisoned = true;
   out8[7] = s->auto_wave ? 1 : 0;
+  if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
   return RGS_OK;
 }
 
 // Diagnostic: per-phase shader-cycle totals of the hybrid kernels since the last reset (or clear).
-// enable: bit 0 = stamps on for later launches, bit 1 = clear the totals first.  out: STAMP_N = 17 values.
-int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out17) {
+// enable: bit 0 = stamps on for later launches, bit 1 = clear the totals first.  out: min(capacity, STAMP_N = 17) values.
+int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out, int capacity) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_get_stamps: null handle");
   HIP_TRY(hipSetDevice(s->device));
   s->stamps = (enable & 1) != 0;
   if (enable & 2) HIP_TRY(hipMemsetAsync(s->counters + CNT_N, 0, sizeof(unsigned long long) * STAMP_N, s->stream));
-  if (out17) {
-    HIP_TRY(hipMemcpyAsync(out17, s->counters + CNT_N, sizeof(unsigned long long) * STAMP_N, hipMemcpyDeviceToHost, s->stream));
+  if (out && capacity > 0) {
+    const int nv = capacity < (int)STAMP_N ? capacity : (int)STAMP_N;
+    HIP_TRY(hipMemcpyAsync(out, s->counters + CNT_N, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   return RGS_OK;
@@ -869,6 +901,18 @@ int rgs_debug_check_guards(rgs_sim *s) {
         }
     }
   }
+  return RGS_OK;
+}
+
+// Debug / test aid: makes the handle look as if a pooled kernel had reported a protocol timeout (device counter
+// CNT_POOL_TIMEOUT = 1), so that the sticky-error path of the synchronising calls can be exercised.
+int rgs_debug_inject_pool_timeout(rgs_sim *s) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_debug_inject_pool_timeout: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  const unsigned long long one = 1ull;
+  HIP_TRY(hipMemcpyAsync(s->counters + CNT_POOL_TIMEOUT, &one, sizeof one, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->pooled_in_flight = true;
   return RGS_OK;
 }
 

@@ -2,6 +2,8 @@
 // kern_n7.o from this file in parallel).  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "gsim_kernels.hpp"
 
 #ifndef GSIM_N
@@ -27,11 +29,18 @@ hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + 64 * kPoolWaves - 1) / (64 * kPoolWaves);
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW * kPoolWaves + sizeof(PoolQueue);
   const void *fn = ASYNC ? (const void *)k_step_apool<N, MODE> : (const void *)k_step_pool<N, MODE>;
-  static bool attr_set = false;                              // > 64 KB of dynamic LDS has to be asked for once (per instantiation)
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // > 64 KB of dynamic LDS has to be asked for once per instantiation AND per device (the attribute belongs to the
+  // device's function object); one bit per device, set after the call succeeded -- a second thread racing here at
+  // worst repeats the (idempotent) call.
+  static std::atomic<unsigned long long> attr_set{0ull};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (dev >= 64 || !(attr_set.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev < 64) attr_set.fetch_or(bit, std::memory_order_release);
   }
   if (ASYNC) hipLaunchKernelGGL((k_step_apool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
   else hipLaunchKernelGGL((k_step_pool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);

@@ -351,7 +351,7 @@ class BatchedGameSim:
     def stamps(self, enable=True, clear=False):
         """Diagnostic: enable/disable in-kernel phase stamps (optionally clearing them) and return the totals so far."""
         out = (C.c_int64 * 17)()
-        _lib.check(self._L.rgs_get_stamps(self._h, int(bool(enable)) | (2 if clear else 0), out))
+        _lib.check(self._L.rgs_get_stamps(self._h, int(bool(enable)) | (2 if clear else 0), out, 17))
         return dict(zip(["lane_cycles", "wave_cycles", "rounds", "total_cycles", "g0_fill", "g0_scan0", "g0_events",
                          "g0_commit", "g0_arenas", "max_total_cycles", "max_wave_cycles", "max_rounds",
                          "max_event_loop_cycles", "ev_head", "ev_carry", "ev_scan", "ev_count"], list(out)))

@@ -56,8 +56,9 @@ SIGNATURES = {
     "rgs_timer_start": (C.c_int, [_vp]),
     "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
-    "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
+    "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "rgs_debug_check_guards": (C.c_int, [_vp]),
+    "rgs_debug_inject_pool_timeout": (C.c_int, [_vp]),
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
     "rgs_set_fast_division": (C.c_int, [_vp, C.c_int]),
     "rgs_set_sparse_watch": (C.c_int, [_vp, C.c_int]),

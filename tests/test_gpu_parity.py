@@ -697,3 +697,22 @@ def test_pooled_kernels_on_ragged_batches(rgp, oracle, variant, B):
     traj = sim.run_table_traj(table, 8)
     assert_same(traj, ref["traj"], "B=%d variant=%d in-kernel snapshots" % (B, variant))
     sim.close()
+
+
+def test_pool_timeout_is_a_sticky_error_until_reset(rgp):
+    """a pooled kernel's bounded wait running out leaves arenas short of their steps; every synchronising
+    call must then fail (not hand out the state with RGS_OK) until the handle is reset."""
+    B, n = 64, 2
+    sim = rgp.BatchedGameSim(B, n)
+    sim.reset(0.05, 3, np.zeros(4))
+    sim.state()                                                    # healthy
+    rgp._lib.check(rgp._lib.lib().rgs_debug_inject_pool_timeout(sim._h))
+    for call in (sim.state, sim.time, sim.damage, sim.undecided, sim.sync, sim.counters,
+                 lambda: sim.step(np.zeros((2 * n, 2, B)))):
+        with pytest.raises(rgp.RgsError) as e:
+            call()
+        assert "timed out" in str(e.value)
+    sim.reset(0.05, 3, np.zeros(4))                                # reset clears counters and the error
+    sim.step(np.zeros((2 * n, 2, B)))
+    assert sim.state().shape == (22, B) and sim.counters()["resolved"] == 0
+    sim.close()
