@@ -133,32 +133,32 @@ def cpu_baseline(orc, w, args, n, x0, amp, ph, cores):
     threads with the reference's 2 normal draws per f_player call (src/GameSim.cpp:66-67).  Each leg's arena count is
     grown from a short calibration run until the leg runs for about `args.cpu_seconds`."""
     P = 2 * n
-    steps = min(max(args.warmup + args.steps, 200), 1010)
-    times = w.step_times(steps, args.dt)
-    cap = min(8192, x0.shape[1])
+    steps0 = min(max(args.warmup + args.steps, 200), 1010)
+    cap = min(16384, x0.shape[1])                                  # arenas; a longer leg then runs more steps (<= 1010)
 
-    def leg(arenas, threads, draw_always):
-        arenas = max(1, min(cap, int(arenas)))
-        tab = w.circle_controls(amp[:, :arenas], ph[:, :arenas], times)
+    def leg(arena_steps, threads, draw_always):
+        arenas = max(1, min(cap, int(arena_steps / steps0)))
+        steps = steps0 if arenas < cap else int(min(1010, max(steps0, arena_steps / cap)))
+        tab = w.circle_controls(amp[:, :arenas], ph[:, :arenas], w.step_times(steps, args.dt))
         if args.config == "c4":
             tab[0] = 0.0                                           # py/MonteCarlo.py:33
         xs = np.ascontiguousarray(x0[:, :arenas])
         t1 = time.perf_counter()
         orc.batch_run(n, xs, tab, steps, dt=args.dt, winning_score=args.win, n_threads=threads, draw_always=draw_always)
         el = time.perf_counter() - t1
-        return arenas, el, arenas * steps / el
+        return (arenas, steps), el, arenas * steps / el
 
     out = {}
     total = 0.0
     for name, threads, draw in (("all", cores, False), ("one", 1, False), ("faithful", cores, True)):
-        arenas, el, rate = leg(8 * threads, threads, draw)         # calibration (also starts the thread pool)
+        shape, el, rate = leg(8 * threads * steps0, threads, draw)  # calibration (also starts the thread pool)
         total += el
         for _ in range(3):                                         # grow the sample until it runs for about cpu_seconds
-            if el >= 0.6 * args.cpu_seconds or arenas >= cap:
+            if el >= 0.6 * args.cpu_seconds or shape == (cap, 1010):
                 break
-            arenas, el, rate = leg(max(arenas + 1, arenas * args.cpu_seconds / max(el, 1e-4)), threads, draw)
+            shape, el, rate = leg(rate * args.cpu_seconds * 1.1, threads, draw)
             total += el
-        out[name] = (arenas, el, rate)
+        out[name] = (shape, el, rate)
     a_all, s_all, r_all = out["all"]
     a_one, s_one, r_one = out["one"]
     a_f, s_f, r_f = out["faithful"]
@@ -166,13 +166,13 @@ def cpu_baseline(orc, w, args, n, x0, amp, ph, cores):
             "cpu_model": cpu_model_string(), "host_cpus": os.cpu_count(),
             "sample": "%d arenas x %d steps of this workload from reset (host-computed controls of the same generator), "
                       "oracle/gamesim_oracle.cpp (g++ -O2 -ffp-contract=off, OpenMP over arenas), dead RNG draws elided"
-                      % (a_all, steps),
+                      % a_all,
             "sample_seconds": round(s_all, 3),
-            "one_thread_value": round(r_one, 1), "one_thread_sample": "%d arenas x %d steps" % (a_one, steps),
+            "one_thread_value": round(r_one, 1), "one_thread_sample": "%d arenas x %d steps" % a_one,
             "one_thread_seconds": round(s_one, 3),
             "reference_faithful_rng_value": round(r_f, 1),
             "reference_faithful_rng_sample": "%d arenas x %d steps, %d threads, 2 normal draws per f_player call as "
-                                             "src/GameSim.cpp:66-67" % (a_f, steps, cores),
+                                             "src/GameSim.cpp:66-67" % (a_f + (cores,)),
             "reference_faithful_rng_seconds": round(s_f, 3), "total_cpu_leg_seconds": round(total, 2)}
 
 

@@ -123,12 +123,10 @@ struct GridView {
       g = 0; e = 0; ax = 0;
     }
 #endif
-    if (SPLITV) {
-      // gv is a raw global pointer: whatever reaches here is kept inside this group's region (LDS accesses
-      // out of range are dropped by the hardware, global ones fault the device)
-      const int gg = g < 0 ? 0 : (g > kGrid ? kGrid : g), ee = e < 0 ? 0 : (e >= E ? E - 1 : e);
-      return gv[gg * (2 * E) + 2 * ee + (ax & 1)];
-    }
+    // (Round 2 clamped these indices after a device fault whose cause was unknown.  The cause was found in round 3: a
+    // hipcc defect that left kernarg OFFSETS stale -- not a grid index -- see DESIGN.md 3.4; tools/isa_lint.py now
+    // rejects any build that shows it, and the clamp, which could only have hidden a wrong index, is gone.)
+    if (SPLITV) return gv[g * (2 * E) + 2 * e + ax];
     return lds[g * CS + 4 * e + 2 + ax];
   }
   __device__ __forceinline__ double &ctl(int e, int ax) const { return lds[U_OFF + 2 * e + ax]; }
