@@ -83,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--jam", action="store_true", help="diagnostic: drive every player towards the arena centre "
                     "(sustained contact, many 49-event steps): the hybrid's worst case")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
+    ap.add_argument("--no-rebalance", action="store_true", help="diagnostic: pooled variants keep every arena on its own workgroup")
     ap.add_argument("--dt", type=float, default=None, help="diagnostic / tools/sweep.py: override the preset's step length")
     args = ap.parse_args(argv)
     preset = PRESETS[args.config]
@@ -242,6 +243,8 @@ def main():
 
     sim = rgp.BatchedGameSim(B, n, device=local_rank)
     sim.set_variant(args.variant)
+    if args.no_rebalance:
+        sim.set_rebalance(False)
     if args.watch_every >= 0:
         sim.set_sparse_watch(args.watch_every)
     mine = torch.empty((S, B), dtype=torch.float64, device=dev)
@@ -269,6 +272,7 @@ def main():
     sim.reset(DT, WIN, np.ascontiguousarray(x0))
     if args.stamps:
         sim.stamps(True)
+        sim.wave_log()                                         # arm the per-wavefront log (asynchronous pool)
     if world > 1:                                             # RCCL channel setup happens on first use: not in the timed region
         all_gather_states(mine if on_dev else mine.cpu(), B * world)
     # ---- warm-up, then the timed region ----------------------------------------------------
@@ -295,8 +299,22 @@ def main():
     total_arena_steps = float(B) * world * K
     value = total_arena_steps / elapsed
     counters = sim.counters()
+    counters["hot_arenas_dealt_to_other_workgroups"] = sim.rebalance_info()[0]
     if args.stamps:
         counters["stamps"] = sim.stamps(True)
+        wl = sim.wave_log()
+        if wl[:, 0].any():
+            np.save(os.path.join(ROOT, "gpurun_out", "wave_log.npy"), wl)
+            wg = wl.reshape(-1, 4, 8)
+            tot = wl[:, 0].astype(float)
+            counters["wave_log"] = {"waves": int(len(wl)), "total_cycles_mean": float(tot.mean()), "total_cycles_max": float(tot.max()),
+                                    "p50": float(np.percentile(tot, 50)), "p90": float(np.percentile(tot, 90)), "p99": float(np.percentile(tot, 99)),
+                                    "own_done_mean": float(wl[:, 5].mean()), "own_done_max": float(wl[:, 5].max()),
+                                    "lane_passes_mean": float(wl[:, 3].mean()), "lane_passes_max": int(wl[:, 3].max()),
+                                    "posted_per_wg_mean": float(wg[:, :, 6].sum(1).mean()), "posted_per_wg_max": int(wg[:, :, 6].sum(1).max()),
+                                    "rounds_per_wg_mean": float(wg[:, :, 4].sum(1).mean()), "rounds_per_wg_max": int(wg[:, :, 4].sum(1).max()),
+                                    "served_per_wg_mean": float(wg[:, :, 7].sum(1).mean()), "served_per_wg_max": int(wg[:, :, 7].sum(1).max()),
+                                    "corr_total_vs_wg_served": float(np.corrcoef(wg[:, :, 0].max(1), wg[:, :, 7].sum(1))[0, 1])}
 
     # ---- sampled arenas: the first cs0 of rank 0 and (N > 1) the first cs1 of the LAST rank, read from the
     # all-gathered ensemble so that the shard -> arena-id mapping of the collective is part of what is checked

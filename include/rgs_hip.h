@@ -157,6 +157,12 @@ int rgs_get_counters(rgs_sim *sim, int64_t *out8);
  * the carry-out, of the carry-out, of the re-scan chunks, and the event count. */
 int rgs_get_stamps(rgs_sim *sim, int enable, int64_t *out, int capacity);   /* writes min(capacity, 17) values */
 
+/* Diagnostic (library built with STAMPS=1, stamps enabled): per-wavefront records of the last asynchronous-pool launch,
+ * out [n_waves][8], n_waves = 4 * ceil(B / 256): cycles in the kernel, in lane passes, serving event-pass rounds, number of
+ * lane passes, rounds served, cycles until the wavefront's own arenas were done, arena-steps posted, arena-steps run for the
+ * pool.  The first call allocates the device buffer (zeros); launches after it fill it. */
+int rgs_debug_wave_log(rgs_sim *sim, int64_t *out, int64_t capacity_waves);
+
 /* Debug aid (GPU AddressSanitizer is not available here): with RGS_DEBUG_GUARD_BYTES=<n> in the environment every
  * device buffer of a handle carries n guard bytes on both sides; this call returns RGS_ERR_HIP and names the first
  * buffer whose guard zone was overwritten.  Without the variable it is a no-op returning RGS_OK. */
@@ -167,6 +173,16 @@ int rgs_debug_check_guards(rgs_sim *sim);
 int rgs_debug_inject_pool_timeout(rgs_sim *sim);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
+
+/* The pooled variants (POOL, APOOL) bind 256 arenas to a workgroup for a launch.  Between fused launches (>= 8 steps,
+ * after >= 4 pooled steps of history) the library deals arenas that spent at least 7/8 of those steps in the event pass
+ * ("hot": lasting contact) evenly over the workgroups by swapping them against cold arenas; results do not depend on
+ * it.  enable = 0 switches the dealing off (default on).  rgs_get_rebalance_info: *n_swapped = hot arenas moved by the
+ * last deal, perm_host (may be NULL) [B] = the arena each lane slot steps (identity when no deal is active). */
+int rgs_set_rebalance(rgs_sim *sim, int enable);
+int rgs_get_rebalance_info(rgs_sim *sim, int *n_swapped, int *perm_host);
+/* heat_host [B]: per arena, the steps of the pooled launches since the last deal that went through the event pass. */
+int rgs_get_heat(rgs_sim *sim, uint32_t *heat_host);
 
 /* Divisions by tau_player / tau_puck use reciprocal sequences that round exactly like IEEE '/'
  * ("Division by tau"): a multiply when tau is a power of two; reciprocal + ONE correction

@@ -127,6 +127,12 @@ struct StepArgs {
   unsigned long long *stamp_out;     // [STAMP_N]
   unsigned long long *counters;      // [CNT_N]
   long long n_state, n_tcur, n_damage;   // element counts of state / tcur / damage (only the COH accessors use them)
+  // Pooled kernels: which arena each lane slot of each workgroup steps (slot = 256 * workgroup + thread; null = the
+  // arena with the slot's own index).  The host deals arenas that spent most of the last launches in the wave pass
+  // evenly over the workgroups (rgs_hip.hip, rebalance): an arena's data never moves, only who computes it.
+  unsigned long long *wave_log;          // diagnostic (STAMPS build, stamps on): 8 values per wavefront of the asynchronous pool
+  const int *perm;
+  unsigned *heat;                        // [B] arena-steps handed to the wave pass since the last deal (null: not counted)
 };
 
 // Global-memory accessors of the per-arena arrays (state, tcur, damage).  Plain loads and stores: an arena is

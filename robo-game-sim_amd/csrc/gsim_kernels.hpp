@@ -162,6 +162,7 @@ struct PoolQueue {                                           // lives in LDS beh
   int front[kPoolWaves];                                     // asynchronous form: step count of each wavefront's most advanced arena
   int lastk[kPoolSlots];                                     // asynchronous form: the arena's last wave-pass step ...
   unsigned char streak[kPoolSlots];                          // ... and how many consecutive steps up to it had a collision
+  int arena[kPoolSlots];                                     // the arena each lane slot of this workgroup steps (StepArgs::perm)
 };
 
 template <typename T>
@@ -175,7 +176,7 @@ __device__ __forceinline__ unsigned long long pool_pack(int local, int k, unsign
          ((unsigned long long)((discmask >> 16) & 63u) << 50);
 }
 
-// One round: claims up to GPW tickets and runs them.  Returns false when the queue had nothing to claim.
+// One round: claims up to GPW tickets and runs them.  Returns the number of tickets run (0: the queue had nothing to claim).
 #ifndef GSIM_POOL_LAGMAX
 #define GSIM_POOL_LAGMAX 32
 #endif
@@ -183,7 +184,7 @@ __device__ __forceinline__ unsigned long long pool_pack(int local, int k, unsign
 #define GSIM_POOL_STREAK 2
 #endif
 template <int N, int FAST, bool ASYNC>
-__device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, const GridView<N, false> &G, long long wg_a0, int lane,
+__device__ __forceinline__ int pool_round(const StepArgs &p, PoolQueue *Q, const GridView<N, false> &G, long long wg_a0, int lane,
                                            int grp, int lg) {
   constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   unsigned h = 0u;
@@ -202,7 +203,7 @@ __device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, cons
   }
   h = (unsigned)__shfl((int)h, 0);
   take = __shfl(take, 0);
-  if (take == 0) return false;
+  if (take == 0) return 0;
   unsigned long long payload = 0ull;
   if (grp < take) {
     const unsigned t = h + (unsigned)grp;
@@ -219,11 +220,11 @@ __device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, cons
   }
   const int local = (int)(payload & 255ull);
   wg_acquire();                                              // the arenas' state, written by the other wavefronts of this CU
-  bool ev = false;
+  unsigned ev = 0u;                                          // arena_step_group's result: bit 0 events, bit 1 overlap predicates seen
   if (grp < take) {
     const int kk = (int)((payload >> 8) & 0x3FFFFFFull);
     const unsigned dm = (unsigned)((payload >> 34) & 0xFFFFull) | ((unsigned)((payload >> 50) & 63ull) << 16);
-    ev = arena_step_group<N, GW, FAST, false, false>(p, p.ctl + (long long)kk * p.ctl_stride, wg_a0 + local, G, lg, lane - lg, dm);
+    ev = arena_step_group<N, GW, FAST, false, false>(p, p.ctl + (long long)kk * p.ctl_stride, (long long)Q->arena[local], G, lg, lane - lg, dm);
   }
   wg_release();                                              // results stored before the home wavefront is told
   if (grp < take && lg == 0) {
@@ -231,13 +232,16 @@ __device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, cons
     if (!ASYNC) {
       __hip_atomic_fetch_add(&Q->pend[local >> 6], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      // Lasting contact (a puck pushed along, discs pressed together): GSIM_POOL_STREAK steps in a row that each
-      // had a collision.  Such an arena would be flagged by every lane pass and make its wavefront wait for
-      // every one of its steps; instead its next step is posted right here and it stays in the wave pass, at
-      // the wave pass' own pace, until a step goes by without a collision (or it gets ahead of its wavefront).
+      // Lasting contact (a puck pushed along, discs pressed together, and just as well a puck RESTING against a player
+      // or a disc sliding along a wall, which resolve nothing but sit inside an overlap predicate at every column):
+      // GSIM_POOL_STREAK steps in a row in which the first scans saw a predicate.  The lane pass' watch is a superset
+      // of the predicates, so such an arena is flagged by every lane pass -- a wasted lane slot, a queue round trip and
+      // a step of lag each time; instead its next step is posted right here and it stays in the wave pass, at the
+      // wave pass' own pace, until a step goes by without a predicate (or it gets ahead of its wavefront).  (Round 2
+      // followed up eventful steps only; the driver window's hot arenas -- pucks resting after a spawn jam -- have none.)
       // Bit 31 of the completion word tells its lane to keep waiting.  Not while trajectories are recorded:
       // the snapshot of step kk is taken by the arena's lane and must see the state of step kk.
-      const unsigned st = !ev ? 0u : (Q->lastk[local] == kk - 1 ? (unsigned)Q->streak[local] + 1u : 1u);
+      const unsigned st = ev == 0u ? 0u : (Q->lastk[local] == kk - 1 ? (unsigned)Q->streak[local] + 1u : 1u);
       Q->streak[local] = (unsigned char)(st > 200u ? 200u : st);
       Q->lastk[local] = kk;
       const bool more = GSIM_POOL_STREAK > 0 && st >= (unsigned)GSIM_POOL_STREAK && p.traj == nullptr && kk + 1 < p.n_steps &&
@@ -248,11 +252,12 @@ __device__ __forceinline__ bool pool_round(const StepArgs &p, PoolQueue *Q, cons
                            __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&Q->seq[tk & (kPoolSlots - 1)], tk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         atomicAdd(&p.counters[CNT_FLAGGED], 1ull);
+        if (p.heat != nullptr) atomicAdd(&p.heat[Q->arena[local]], 1u);
       }
       __hip_atomic_store(&Q->fin[local], (unsigned)(kk + 1) | (more ? 0x80000000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  return true;
+  return take;                                               // arena-steps run by this round (> 0)
 }
 
 template <int N, int MODE>
@@ -263,11 +268,11 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / GW, lg = lane % GW;
   const long long wg_a0 = (long long)blockIdx.x * (64 * kPoolWaves);
-  const long long a = wg_a0 + threadIdx.x;
-  const bool mine = a < p.B;
+  const bool mine = wg_a0 + threadIdx.x < p.B;
+  const long long a = (mine && p.perm != nullptr) ? (long long)p.perm[wg_a0 + threadIdx.x] : wg_a0 + threadIdx.x;
   const GridView<N, false> G{lds + (wave * GPW + grp) * WaveLayout<N>::DOUBLES, nullptr GSIM_GRID_DBG(p)};
   PoolQueue *Q = (PoolQueue *)(lds + kPoolWaves * GPW * WaveLayout<N>::DOUBLES);
-  if (threadIdx.x < kPoolSlots) Q->seq[threadIdx.x] = 0u;
+  if (threadIdx.x < kPoolSlots) { Q->seq[threadIdx.x] = 0u; Q->arena[threadIdx.x] = (int)a; }
   if (threadIdx.x < kPoolWaves) Q->pend[threadIdx.x] = 0;
   if (threadIdx.x == 0) { Q->tail = 0u; Q->head = 0u; Q->done = 0u; }
   __syncthreads();
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
     if (n != 0) {
       wg_release();                                          // these arenas' state as of step k is stored before they are offered
       unsigned tk = 0u;
+      if (slow && p.heat != nullptr) atomicAdd(&p.heat[a], 1u);
       if (lane == 0) {
         atomicAdd(&p.counters[CNT_FLAGGED], (unsigned long long)n);
         __hip_atomic_store(&Q->pend[wave], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -376,11 +382,11 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / GW, lg = lane % GW;
   const long long wg_a0 = (long long)blockIdx.x * (64 * kPoolWaves);
-  const long long a = wg_a0 + threadIdx.x;
-  const bool mine = a < p.B;
+  const bool mine = wg_a0 + threadIdx.x < p.B;
+  const long long a = (mine && p.perm != nullptr) ? (long long)p.perm[wg_a0 + threadIdx.x] : wg_a0 + threadIdx.x;
   const GridView<N, false> G{lds + (wave * GPW + grp) * WaveLayout<N>::DOUBLES, nullptr GSIM_GRID_DBG(p)};
   PoolQueue *Q = (PoolQueue *)(lds + kPoolWaves * GPW * WaveLayout<N>::DOUBLES);
-  if (threadIdx.x < kPoolSlots) { Q->seq[threadIdx.x] = 0u; Q->fin[threadIdx.x] = 0u; Q->streak[threadIdx.x] = 0; Q->lastk[threadIdx.x] = -2; }
+  if (threadIdx.x < kPoolSlots) { Q->seq[threadIdx.x] = 0u; Q->fin[threadIdx.x] = 0u; Q->streak[threadIdx.x] = 0; Q->lastk[threadIdx.x] = -2; Q->arena[threadIdx.x] = (int)a; }
   if (threadIdx.x < kPoolWaves) { Q->pend[threadIdx.x] = 0; Q->front[threadIdx.x] = 0; }
   if (threadIdx.x == 0) { Q->tail = 0u; Q->head = 0u; Q->done = 0u; }
   __syncthreads();
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
   bool busy = false;                                         // its step kl is with the wave pass
   unsigned seen_head = 0xFFFFFFFFu;
   int seen_times = 0, waits = 0;
-  unsigned long long n_iter = 0;
+  unsigned long long n_iter = 0, t_main = 0, n_posted = 0, n_served_arenas = 0;
   for (;;) {
     // completions of posted tasks
     unsigned fw = 0u;
@@ -433,6 +439,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
     const unsigned long long m = __ballot(post);
     if (m != 0ull) {
       const int n = __builtin_popcountll(m);
+      if (GSIM_STAMPS) n_posted += (unsigned long long)n;
       wg_release();                                          // these arenas' state as of their step is stored before they are offered
       unsigned tk = 0u;
       if (lane == 0) {
@@ -440,6 +447,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
         tk = __hip_atomic_fetch_add(&Q->tail, (unsigned)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       tk = (unsigned)__shfl((int)tk, 0) + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (slow && p.heat != nullptr) atomicAdd(&p.heat[a], 1u);
       if (post) {
         __hip_atomic_store(&Q->task[tk & (kPoolSlots - 1)], pool_pack((int)threadIdx.x, kl, discmask), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
       if (avail <= 0) { seen_times = 0; seen_head = 0xFFFFFFFFu; break; }
       if (h == seen_head) seen_times++; else { seen_head = h; seen_times = 1; }
       if (avail < GPW && can_step && seen_times < GSIM_POOL_AGE) break;
-      if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; served = true; }
+      if (const int got = pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; served = true; if (GSIM_STAMPS) n_served_arenas += (unsigned long long)got; }
       seen_times = 0; seen_head = 0xFFFFFFFFu;
       if (can_step) break;                                   // one round per lane pass while there are lane passes to do
     }
@@ -477,12 +485,13 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
     }
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
   }
+  if (GSIM_STAMPS && p.stamps) t_main = __builtin_amdgcn_s_memtime() - t_begin;
   // this wavefront's arenas are done; keep serving its siblings until all four are (they are resident: bounded)
   if (lane == 0) __hip_atomic_fetch_add(&Q->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   // (as in k_step_pool: a timeout here only ends this wavefront's help and is not an error)
   unsigned seen_done = 0u;
   for (int spins = 0;;) {
-    if (pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; spins = 0; continue; }
+    if (const int got = pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; spins = 0; if (GSIM_STAMPS) n_served_arenas += (unsigned long long)got; continue; }
     unsigned done = 0u;
     if (lane == 0) done = lds_ld(&Q->done);
     done = (unsigned)__shfl((int)done, 0);
@@ -500,6 +509,10 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
     atomicMax(&p.stamp_out[STAMP_MAX_TOTAL], t_all);
     atomicMax(&p.stamp_out[STAMP_MAX_WAVE], t_wave);
     atomicMax(&p.stamp_out[STAMP_MAX_ROUNDS], n_iter);   // here: lane passes of the slowest wavefront
+    if (p.wave_log != nullptr) {                         // per-wavefront record for tools/wave_log.py
+      unsigned long long *w = p.wave_log + 8ull * ((unsigned long long)blockIdx.x * kPoolWaves + wave);
+      w[0] = t_all; w[1] = t_lane; w[2] = t_wave; w[3] = n_iter; w[4] = n_rounds; w[5] = t_main; w[6] = n_posted; w[7] = n_served_arenas;
+    }
   }
 }
 

@@ -466,8 +466,10 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // a disc outside the mask provably has no candidate in the first scan, so that scan is skipped;
 // bits 16..21 = first grid column that can hold a candidate (1 when unknown), where the first scans
 // start.
-// Returns without touching anything if the game is already decided (cpp:121-123); the return value says
-// whether the step had any collision event.
+// Returns without touching anything if the game is already decided (cpp:121-123).  Return value (group-uniform):
+// bit 0 = the step had a collision event, bit 1 = the first scans saw an overlap predicate of a considered disc at
+// some column (a disc in a wall zone, a pair within reach): the lane pass' watch, a superset of those predicates,
+// would have flagged this step.
 //
 // NOISE (w_stdev_ != 0): every RK4 of a player consumes 8 draws of the arena's tape in the reference's
 // call order -- populateStateGrid: column by column, A1..Bn (cpp:199-215); carryOutFirstCollision:
@@ -476,14 +478,14 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
 template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false, bool COH = false>
-__device__ bool arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
+__device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
                                  const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
   constexpr int E = L::E, PK = L::PK;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
   const long long B = p.B;
   double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
-  if (!(TAS < p.win && TBS < p.win)) return false;           // undecided(), cpp:57-60,121
+  if (!(TAS < p.win && TBS < p.win)) return 0u;              // undecided(), cpp:57-60,121
   const double t0 = gld_at<COH>(p.tcur, a, p.n_tcur);
   const double dt = p.dt, dt_col = p.dt_col;
   const double *tape = NOISE ? p.tape + p.tape_off[a] : nullptr;
@@ -527,6 +529,7 @@ __device__ bool arena_step_group(const StepArgs &p, const double *__restrict__ c
   int seq = 0, base = 1, counter = 0;
   bool scored = false;
   unsigned n_resolved = 0, n_skipped = 0, n_overflow = 0;
+  bool saw_predicate = false;
   // First pass, checks = all discs (cpp:145 -> insertCollisions): lane <-> grid column.  Each chunk of
   // GW columns first gets the overlap predicates of every disc in one straight-line pass
   // (column_flags); only (disc, column) pairs with a predicate set can yield a candidate, so only those
@@ -544,6 +547,7 @@ __device__ bool arena_step_group(const StepArgs &p, const double *__restrict__ c
       const int g = g0 + lg;
       const unsigned fl = g <= kGrid ? (column_flags<N, SPLITV>(p, G, g, consider) & open) : 0u;
       if (group_ballot<GW>(fl != 0u, gbase) == 0ull) continue;
+      saw_predicate = true;
       unsigned todo = 0u;                                    // union of the lanes' flags (group-uniform)
 #pragma unroll
       for (int e = 0; e < E; ++e) todo |= group_ballot<GW>(((fl >> e) & 1u) != 0u, gbase) != 0ull ? (1u << e) : 0u;
@@ -826,7 +830,7 @@ __device__ bool arena_step_group(const StepArgs &p, const double *__restrict__ c
     atomicAdd(&p.stamp_out[STAMP_COMMIT], ts4 - ts3);
     atomicAdd(&p.stamp_out[STAMP_ARENAS], 1ull);
   }
-  return had_events;                                         // group-uniform: the step found at least one collision
+  return (had_events ? 1u : 0u) | (saw_predicate ? 2u : 0u);
 }
 
 }  // namespace gsim

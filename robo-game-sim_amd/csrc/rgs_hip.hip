@@ -51,6 +51,108 @@ __global__ void k_undecided(const double *state, long long B, double win, uint8_
   out[a] = (state[a] < win && state[B + a] < win) ? 1 : 0;
 }
 
+// ---- dealing hot arenas evenly over the pooled kernels' workgroups (see rebalance() below) ----
+constexpr int kDealWG = 256;     // arenas per workgroup of the pooled kernels (64 * kPoolWaves)
+constexpr int kDealMax = 64;     // arenas one workgroup gives away or takes in per deal
+
+// One block per FULL workgroup w of the pooled kernels: resets its slots to the identity deal, counts the hot arenas
+// (heat >= thr) among its own 256, lists the first kDealMax hot and the first kDealMax cold slots in slot order
+// (deterministic), and clears the heat for the next window.
+__global__ void k_deal_scan(const unsigned *heat_in, unsigned *heat_clear, int *perm, unsigned thr, int *hot_count, int *hot_list,
+                            int *cold_list) {
+  __shared__ int wave_hot[4], wave_cold[4];
+  const int w = blockIdx.x, t = threadIdx.x;
+  const long long slot = (long long)w * kDealWG + t;
+  const bool hot = heat_in[slot] >= thr;
+  perm[slot] = (int)slot;
+  heat_clear[slot] = 0u;
+  const unsigned long long mh = __ballot(hot), mc = __ballot(!hot);
+  const int wave = t >> 6, lane = t & 63;
+  if (lane == 0) { wave_hot[wave] = __builtin_popcountll(mh); wave_cold[wave] = __builtin_popcountll(mc); }
+  __syncthreads();
+  int bh = 0, bc = 0, nh = 0;
+  for (int q = 0; q < 4; ++q) { if (q < wave) { bh += wave_hot[q]; bc += wave_cold[q]; } nh += wave_hot[q]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int ih = bh + __builtin_popcountll(mh & below), ic = bc + __builtin_popcountll(mc & below);
+  if (hot && ih < kDealMax) hot_list[w * kDealMax + ih] = (int)slot;
+  if (!hot && ic < kDealMax) cold_list[w * kDealMax + ic] = (int)slot;
+  if (t == 0) hot_count[w] = nh;
+}
+
+// One block of 1024 threads levels the hot arenas: with total = q * n_wg + r every workgroup should end with q or q + 1.
+// Gives, in this order: first everything above q + 1 ("must"), then the one between q + 1 and q ("may"); places
+// likewise: first the ones up to q, then the one from q to q + 1.  The k-th give meets the k-th place and
+// max(sum of must-gives, sum of must-places) swaps are made, which is enough for both musts and never takes a workgroup
+// outside [q, q + 1] (a first version matched surplus above ceil(avg) against places below it in workgroup order: the
+// first takers filled up, the last ones stayed at 3 of 11).  perm[hot slot] <-> perm[cold slot]; at most kDealMax per
+// workgroup and deal.  Thread t owns workgroups [t*per, (t+1)*per); sums and prefix sums go through LDS (one thread
+// walking hot_count[] in global memory cost 0.3 ms).
+__global__ void k_deal_match(const int *hot_count, const int *hot_list, const int *cold_list, int n_wg, int per, int *perm,
+                             unsigned *heat_tail, int *n_swapped) {
+  extern __shared__ int sh[];                           // 4 exclusive prefix arrays of n_wg + 1: must-give, may-give, must-take, may-take
+  int *pre[4] = {sh, sh + (n_wg + 1), sh + 2 * (n_wg + 1), sh + 3 * (n_wg + 1)};
+  __shared__ int part[4][1024];
+  __shared__ int q_sh;
+  const int t = threadIdx.x, w0 = t * per, w1 = (w0 + per < n_wg) ? w0 + per : n_wg;
+  for (int i = t; i < kDealWG; i += blockDim.x) { perm[n_wg * kDealWG + i] = n_wg * kDealWG + i; heat_tail[i] = 0u; }   // ragged last workgroup
+  int sum = 0;
+  for (int w = w0; w < w1; ++w) sum += hot_count[w];
+  part[0][t] = sum;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) { if (t < off) part[0][t] += part[0][t + off]; __syncthreads(); }
+  if (t == 0) q_sh = part[0][0] / n_wg;
+  __syncthreads();
+  const int q = q_sh;
+  auto amounts = [&](int h, int *v) {                   // this workgroup's must-give, may-give, must-take, may-take
+    const int cap_give = h < kDealMax ? h : kDealMax, cold = kDealWG - h, cap_take = cold < kDealMax ? cold : kDealMax;
+    int mg = h > q + 1 ? h - (q + 1) : 0, yg = h >= q + 1 ? 1 : 0, mt = h < q ? q - h : 0, yt = h <= q ? 1 : 0;
+    mg = mg < cap_give ? mg : cap_give; yg = (mg + yg <= cap_give) ? yg : 0;
+    mt = mt < cap_take ? mt : cap_take; yt = (mt + yt <= cap_take) ? yt : 0;
+    v[0] = mg; v[1] = yg; v[2] = mt; v[3] = yt;
+  };
+  int mine[4] = {0, 0, 0, 0};
+  for (int w = w0; w < w1; ++w) { int v[4]; amounts(hot_count[w], v); for (int c = 0; c < 4; ++c) mine[c] += v[c]; }
+  __syncthreads();
+  for (int c = 0; c < 4; ++c) part[c][t] = mine[c];
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {            // inclusive Hillis-Steele scans
+    int v[4];
+    for (int c = 0; c < 4; ++c) v[c] = t >= off ? part[c][t - off] : 0;
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) part[c][t] += v[c];
+    __syncthreads();
+  }
+  int run[4];
+  for (int c = 0; c < 4; ++c) run[c] = part[c][t] - mine[c];
+  for (int w = w0; w < w1; ++w) {
+    int v[4]; amounts(hot_count[w], v);
+    for (int c = 0; c < 4; ++c) { pre[c][w] = run[c]; run[c] += v[c]; }
+  }
+  if (t == 1023) for (int c = 0; c < 4; ++c) pre[c][n_wg] = part[c][1023];
+  __syncthreads();
+  const int must_give = pre[0][n_wg], must_take = pre[2][n_wg];
+  int m = must_give > must_take ? must_give : must_take;          // <= must + may on either side (sum of h = q*n_wg + r) ...
+  const int all_give = must_give + pre[1][n_wg], all_take = must_take + pre[3][n_wg];
+  m = m < all_give ? m : all_give;                                // ... unless the per-deal cap of a workgroup cut its amounts
+  m = m < all_take ? m : all_take;
+  if (t == 0) *n_swapped = m;
+  auto owner = [&](const int *p, int r, int &w, int &j) {         // largest w with p[w] <= r; j = r - p[w]
+    int lo = 0, hi = n_wg;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p[mid] <= r) lo = mid; else hi = mid; }
+    w = lo; j = r - p[lo];
+  };
+  for (int r = t; r < m; r += blockDim.x) {
+    int wg, jg, wt, jt;
+    if (r < must_give) owner(pre[0], r, wg, jg);
+    else { owner(pre[1], r - must_give, wg, jg); int v[4]; amounts(hot_count[wg], v); jg += v[0]; }       // after its must-gives
+    if (r < must_take) owner(pre[2], r, wt, jt);
+    else { owner(pre[3], r - must_take, wt, jt); int v[4]; amounts(hot_count[wt], v); jt += v[2]; }       // after its must-takes
+    const int hot_slot = hot_list[wg * kDealMax + jg], cold_slot = cold_list[wt * kDealMax + jt];
+    perm[hot_slot] = cold_slot;                         // the identity deal was just restored: slot s held arena s
+    perm[cold_slot] = hot_slot;
+  }
+}
+
 __global__ void k_selftest_divtau(const double *a, long long n, double tau, double inv, double *fast, double *ieee,
                                   double *one) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,6 +223,14 @@ struct rgs_sim {
   int n_cus = 256;                 // hipDeviceProp_t::multiProcessorCount
   // Pooled kernels report a bounded wait that ran out in counters[CNT_POOL_TIMEOUT]: arenas may then be short of
   // their steps.  The error is sticky: every synchronising call checks it (finish()) and fails until the next reset.
+  // Dealing hot arenas over the pooled kernels' workgroups (rebalance()): perm[slot] = arena, heat[arena] = arena-steps
+  // handed to the wave pass in the pooled launches since the last deal.
+  int *perm = nullptr, *hot_count = nullptr, *hot_list = nullptr, *cold_list = nullptr, *n_swapped = nullptr;
+  unsigned *heat = nullptr;
+  bool perm_valid = false;         // perm holds a deal (else the kernels get a null perm = identity)
+  bool deal_enabled = true;        // rgs_set_rebalance
+  long long heat_steps = 0;        // pooled steps counted into heat since the last deal
+  unsigned long long *wave_log = nullptr;   // diagnostic: per-wavefront records of the asynchronous pool (stamps on)
   bool pooled_in_flight = false;   // a pooled launch has been queued since the counters were last looked at
   bool poisoned = false;
   unsigned long long *counters_pin = nullptr;   // page-locked mirror of the CNT_N counters
@@ -399,6 +509,48 @@ int noise_step(rgs_sim *s, StepArgs a) {
   return RGS_OK;
 }
 
+// Pooled kernels bind 256 arenas to a workgroup (= a CU) for a whole launch, and an arena in lasting contact (a puck
+// resting against a player, a disc pressed into a wall) needs the wave pass at EVERY step for tens to hundreds of steps:
+// where such arenas cluster, their CU finishes last (driver window of bench.py: 12 to 36 of them per workgroup, the
+// slowest wavefront 1.27x the average).  Between launches the arenas are therefore dealt afresh: an arena that went
+// to the wave pass in at least 7/8 of the steps since the last deal is "hot"; workgroups above the average number
+// of hot arenas swap their surplus against cold arenas of workgroups below it.  Only the swapped lanes (about 1 % of
+// them) leave the coalesced arena order -- a full re-ordering by heat was measured in round 1 and lost 27 % to the
+// scattered state accesses.  An arena's data never moves and its arithmetic does not depend on who runs it: results are
+// bit-identical with and without (tests/test_gpu_parity.py::test_hot_arenas_are_dealt_evenly...).
+int rebalance(rgs_sim *s, int n_steps) {
+  const int n_wg = (int)(s->B / kDealWG);                     // full workgroups only; a ragged last one keeps its arenas
+  if (!s->deal_enabled || n_wg < 2) return RGS_OK;
+  if (!s->perm) {
+    const size_t slots = (size_t)(n_wg + 1) * kDealWG;
+    HIP_TRY(dev_alloc(s, &s->perm, sizeof(int) * slots, "perm"));
+    HIP_TRY(dev_alloc(s, &s->heat, sizeof(unsigned) * slots, "heat"));
+    HIP_TRY(dev_alloc(s, &s->hot_count, sizeof(int) * n_wg, "hot_count"));
+    HIP_TRY(dev_alloc(s, &s->hot_list, sizeof(int) * (size_t)n_wg * kDealMax, "hot_list"));
+    HIP_TRY(dev_alloc(s, &s->cold_list, sizeof(int) * (size_t)n_wg * kDealMax, "cold_list"));
+    HIP_TRY(dev_alloc(s, &s->n_swapped, sizeof(int), "n_swapped"));
+    HIP_TRY(hipMemsetAsync(s->heat, 0, sizeof(unsigned) * slots, s->stream));
+    HIP_TRY(hipMemsetAsync(s->n_swapped, 0, sizeof(int), s->stream));
+    s->heat_steps = 0; s->perm_valid = false;
+  }
+  // a new deal needs a few steps of history and is only worth its two small launches ahead of a fused launch
+  if (s->heat_steps >= 4 && n_steps >= 8) {
+    // "hot" = in the event pass at (nearly) every step of the window: measured on the driver's shape (tools/heat_probe.py),
+    // arenas flagged at 5 of 5 warm-up steps carry 89 % of the next steps' event-pass work (5.6 of 7 steps each), those
+    // flagged at 3 or 4 of 5 carry 0.4 of 7 -- counting them as hot (an earlier ">= half" rule) dealt the wrong arenas
+    const unsigned thr = (unsigned)(s->heat_steps - s->heat_steps / 8);
+    hipLaunchKernelGGL(k_deal_scan, dim3((unsigned)n_wg), dim3(kDealWG), 0, s->stream, s->heat, s->heat, s->perm, thr, s->hot_count,
+                       s->hot_list, s->cold_list);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_deal_match, dim3(1), dim3(1024), sizeof(int) * 4 * (n_wg + 1), s->stream, s->hot_count, s->hot_list,
+                       s->cold_list, n_wg, (n_wg + 1023) / 1024, s->perm, s->heat + (size_t)n_wg * kDealWG, s->n_swapped);
+    HIP_TRY(hipGetLastError());
+    s->heat_steps = 0;
+    s->perm_valid = true;
+  }
+  return RGS_OK;
+}
+
 int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps, double *traj = nullptr,
                  int traj_every = 0) {
   StepArgs a{};
@@ -442,6 +594,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.sigma = 0.0; a.tape = nullptr; a.tape_off = nullptr; a.tape_n = nullptr; a.consumed = nullptr; a.vgrid = nullptr;
+  a.perm = nullptr; a.heat = nullptr; a.wave_log = s->stamps ? s->wave_log : nullptr;
   a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
   if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
@@ -538,8 +691,14 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.vgrid = s->vgrid;
     return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
   }
-  if (variant == RGS_VARIANT_POOL && n_steps < (1 << 26)) { s->pooled_in_flight = true; return launch_kind(s, a, LAUNCH_POOL, div_mode); }
-  if (variant == RGS_VARIANT_APOOL && n_steps < (1 << 26)) { s->pooled_in_flight = true; return launch_kind(s, a, LAUNCH_APOOL, div_mode); }
+  if ((variant == RGS_VARIANT_POOL || variant == RGS_VARIANT_APOOL) && n_steps < (1 << 26)) {
+    RGS_TRY(rebalance(s, n_steps));
+    a.perm = s->perm_valid ? s->perm : nullptr;
+    a.heat = s->heat;                                          // null while dealing is off or the batch is a single workgroup
+    if (s->heat) s->heat_steps += n_steps;
+    s->pooled_in_flight = true;
+    return launch_kind(s, a, variant == RGS_VARIANT_POOL ? LAUNCH_POOL : LAUNCH_APOOL, div_mode);
+  }
   if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
   return launch_kind(s, a, LAUNCH_WAVE, !fast ? 0 : (s->one_step_ok ? 3 : 1));
 
@@ -604,6 +763,17 @@ int rgs_create(int64_t n_arenas, int n_per_team, int device_id, rgs_sim **out) {
   const double zero[4] = {0, 0, 0, 0};
   s->one_step_ok = one_step_certified(s->tau_player) && one_step_certified(s->tau_puck);
   int rc = do_reset(s, zero, 0);                 // C++ defaults, src/GameSim.cpp:21-25
+  if (rc == RGS_OK && s->B / kDealWG >= 2) {     // dealing buffers now, and one empty deal so that the first real one finds
+    rc = rebalance(s, 0);                        // its two kernels' code object loaded (0.3 ms otherwise, inside somebody's timed launch)
+    if (rc == RGS_OK) {
+      const int n_wg = (int)(s->B / kDealWG);
+      hipLaunchKernelGGL(k_deal_scan, dim3((unsigned)n_wg), dim3(kDealWG), 0, s->stream, s->heat, s->heat, s->perm, 0xFFFFFFFFu,
+                         s->hot_count, s->hot_list, s->cold_list);
+      hipLaunchKernelGGL(k_deal_match, dim3(1), dim3(1024), sizeof(int) * 4 * (n_wg + 1), s->stream, s->hot_count, s->hot_list,
+                         s->cold_list, n_wg, (n_wg + 1023) / 1024, s->perm, s->heat + (size_t)n_wg * kDealWG, s->n_swapped);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(RGS_ERR_HIP, "rgs_create: dealing kernels");
+    }
+  }
   if (rc != RGS_OK) { rgs_destroy(s); return rc; }
   *out = s;
   return RGS_OK;
@@ -614,6 +784,7 @@ int rgs_destroy(rgs_sim *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
+  dev_free(s, s->wave_log); dev_free(s, s->perm); dev_free(s, s->heat); dev_free(s, s->hot_count); dev_free(s, s->hot_list); dev_free(s, s->cold_list); dev_free(s, s->n_swapped);
   dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->tapeoff_dev); dev_free(s, s->tapen_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
   if (s->counters_pin) hipHostFree(s->counters_pin);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -645,6 +816,8 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
   }
   s->sigma = noise;
   s->poisoned = false; s->pooled_in_flight = false;
+  s->perm_valid = false; s->heat_steps = 0;                   // a reset game has no contact history: identity deal
+  if (s->heat) HIP_TRY(hipMemsetAsync(s->heat, 0, sizeof(unsigned) * (size_t)(s->B / kDealWG + 1) * kDealWG, s->stream));
   s->auto_wave = false; s->window_steps = 0; s->seen_busy = 0;
   s->one_step_ok = s->one_step_enabled && one_step_certified(tau_player) && one_step_certified(tau_puck);
   s->dt = dt;
@@ -882,6 +1055,23 @@ int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out, int capacity) {
 }
 
 // Debug (RGS_DEBUG_GUARD_BYTES=n): verifies the 0xA5 guard zones around every device buffer of the handle.
+// Diagnostic (library built with STAMPS=1, stamps enabled): 8 values per wavefront of the last asynchronous-pool launch:
+// cycles in the kernel, in lane passes, serving rounds, lane passes, rounds served, cycles until its own arenas were
+// done, arena-steps it posted, arena-steps it ran for the pool.  out: [n_waves][8], n_waves = 4 * ceil(B / 256).
+int rgs_debug_wave_log(rgs_sim *s, int64_t *out, int64_t capacity_waves) {
+  if (!s || !out) return fail(RGS_ERR_ARG, "rgs_debug_wave_log: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const long long n_waves = 4 * ((s->B + kDealWG - 1) / kDealWG);
+  if (capacity_waves < n_waves) return fail(RGS_ERR_ARG, "rgs_debug_wave_log: buffer too small");
+  if (!s->wave_log) {                                          // first call: allocate; later launches fill it
+    HIP_TRY(dev_alloc(s, &s->wave_log, sizeof(unsigned long long) * 8 * n_waves, "wave_log"));
+    HIP_TRY(hipMemsetAsync(s->wave_log, 0, sizeof(unsigned long long) * 8 * n_waves, s->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(out, s->wave_log, sizeof(unsigned long long) * 8 * n_waves, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
 int rgs_debug_check_guards(rgs_sim *s) {
   if (!s) return fail(RGS_ERR_ARG, "rgs_debug_check_guards: null handle");
   const size_t g = guard_bytes();
@@ -919,6 +1109,34 @@ int rgs_debug_inject_pool_timeout(rgs_sim *s) {
 int rgs_set_variant(rgs_sim *s, int variant) {
   if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_APOOL) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
+  return RGS_OK;
+}
+
+int rgs_set_rebalance(rgs_sim *s, int enable) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_set_rebalance: null handle");
+  s->deal_enabled = enable != 0;
+  if (!s->deal_enabled) s->perm_valid = false;
+  return RGS_OK;
+}
+
+int rgs_get_heat(rgs_sim *s, uint32_t *heat_host) {
+  if (!s || !heat_host) return fail(RGS_ERR_ARG, "rgs_get_heat: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (!s->heat) { for (long long i = 0; i < s->B; ++i) heat_host[i] = 0u; return RGS_OK; }
+  HIP_TRY(hipMemcpyAsync(heat_host, s->heat, sizeof(unsigned) * (size_t)s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RGS_OK;
+}
+
+int rgs_get_rebalance_info(rgs_sim *s, int *n_swapped, int *perm_host) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_get_rebalance_info: null handle");
+  HIP_TRY(hipSetDevice(s->device));
+  if (n_swapped) *n_swapped = 0;
+  if (perm_host) for (long long i = 0; i < s->B; ++i) perm_host[i] = (int)i;
+  if (!s->perm || !s->perm_valid) return RGS_OK;
+  if (n_swapped) HIP_TRY(hipMemcpyAsync(n_swapped, s->n_swapped, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  if (perm_host) HIP_TRY(hipMemcpyAsync(perm_host, s->perm, sizeof(int) * (size_t)(s->B / kDealWG) * kDealWG, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return RGS_OK;
 }
 

@@ -356,12 +356,37 @@ class BatchedGameSim:
                          "g0_commit", "g0_arenas", "max_total_cycles", "max_wave_cycles", "max_rounds",
                          "max_event_loop_cycles", "ev_head", "ev_carry", "ev_scan", "ev_count"], list(out)))
 
+    def wave_log(self):
+        """Diagnostic (stamps library, stamps on): (n_waves, 8) int64 records of the last asynchronous-pool launch; the
+        first call only arms the log."""
+        nw = 4 * ((self.n_arenas + 255) // 256)
+        out = np.zeros((nw, 8), dtype=np.int64)
+        _lib.check(self._L.rgs_debug_wave_log(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), nw))
+        return out
+
     def check_guards(self):
         """Debug: raises if a device buffer's guard zone was overwritten (needs RGS_DEBUG_GUARD_BYTES in the environment)."""
         _lib.check(self._L.rgs_debug_check_guards(self._h))
 
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
+
+    def set_rebalance(self, enable):
+        """Pooled variants: deal arenas in lasting contact evenly over the workgroups between fused launches (default on)."""
+        _lib.check(self._L.rgs_set_rebalance(self._h, int(bool(enable))))
+
+    def rebalance_info(self):
+        """(hot arenas moved by the last deal, perm (B,) int32: the arena each lane slot steps)."""
+        n = C.c_int(0)
+        perm = np.empty(self.n_arenas, dtype=np.int32)
+        _lib.check(self._L.rgs_get_rebalance_info(self._h, C.byref(n), perm.ctypes.data_as(C.POINTER(C.c_int))))
+        return int(n.value), perm
+
+    def heat(self):
+        """(B,) uint32: steps of the pooled launches since the last deal in which the arena went through the event pass."""
+        out = np.zeros(self.n_arenas, dtype=np.uint32)
+        _lib.check(self._L.rgs_get_heat(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
 
     def set_fast_division(self, level):
         """0/False: IEEE division everywhere; 1: reciprocal with two correction steps; 2/True: also the

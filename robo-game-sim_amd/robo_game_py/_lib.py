@@ -58,8 +58,12 @@ SIGNATURES = {
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "rgs_debug_check_guards": (C.c_int, [_vp]),
+    "rgs_debug_wave_log": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int64]),
     "rgs_debug_inject_pool_timeout": (C.c_int, [_vp]),
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
+    "rgs_set_rebalance": (C.c_int, [_vp, C.c_int]),
+    "rgs_get_heat": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "rgs_get_rebalance_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgs_set_fast_division": (C.c_int, [_vp, C.c_int]),
     "rgs_set_sparse_watch": (C.c_int, [_vp, C.c_int]),
     "rgs_division_info": (C.c_int, [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.c_int,

@@ -716,3 +716,55 @@ def test_pool_timeout_is_a_sticky_error_until_reset(rgp):
     sim.step(np.zeros((2 * n, 2, B)))
     assert sim.state().shape == (22, B) and sim.counters()["resolved"] == 0
     sim.close()
+
+
+@pytest.mark.parametrize("variant", [4, 5], ids=["pool", "apool"])
+def test_hot_arenas_are_dealt_evenly_and_results_do_not_change(rgp, oracle, variant):
+    """Pooled kernels: arenas in lasting contact (here: pucks spawned inside a player, all of them in the first two
+    workgroups) are dealt over the workgroups between fused launches.  The deal must be a permutation that evens out
+    the hot arenas, and every value must stay the oracle's -- with the dealing on, off, and across several deals."""
+    from robo_game_py import workloads as w
+    n, dt, B = 2, 0.01, 8 * 256 + 37
+    x0, amp, ph = w.c2_inputs(B, n, seed=77)
+    x0 = x0 * np.array([0.3, 0.3, 0.05, 0.05])[:, None]            # calm pucks near the centre ...
+    hot = np.arange(B) < 400                                       # ... except 400 spawned inside player A1, at rest
+    x0[:, hot] = np.array([[-2.5 + 0.05], [1.25 + 0.02], [0.0], [0.0]])
+    K = 6 + 12 + 12 + 3
+    table = w.circle_controls(amp * 0.2, ph, w.step_times(K, dt))
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, want_damage=True)
+    stride = 2 * n * 2 * B
+    finals = []
+    for dealing in (True, False):
+        sim = rgp.BatchedGameSim(B, n)
+        sim.set_variant(variant)
+        sim.set_rebalance(dealing)
+        sim.reset(dt, 1000, x0)
+        buf = sim.alloc(K * stride)
+        buf.upload(table)
+        moved = []
+        k = 0
+        for m in (6, 12, 12, 3):                                   # history, first deal, second deal, a short launch (no deal)
+            sim.step_device(buf.ptr + 8 * k * stride, stride, m)
+            k += m
+            nsw, perm = sim.rebalance_info()
+            moved.append(nsw)
+            assert sorted(perm.tolist()) == list(range(B)), "the deal is not a permutation"
+            assert np.array_equal(perm[8 * 256:], np.arange(8 * 256, B)), "the ragged last workgroup keeps its arenas"
+            if dealing and nsw:
+                per_wg = np.array([np.count_nonzero(hot[perm[q * 256:(q + 1) * 256]]) for q in range(8)])
+                # 256 + 144 hot arenas in workgroups 0 and 1, average 50: each gives its 64-arena maximum per deal,
+                # the 128 go to the first open places of the workgroups below the average (50, 50, 28)
+                assert per_wg.tolist() == [192, 80, 50, 50, 28, 0, 0, 0], per_wg
+                assert nsw == 128
+        got = sim.state()
+        assert_same(got, ref["state"], "variant %d dealing %s" % (variant, dealing))
+        assert_same(sim.damage().reshape(4 * n * n, B), ref["damage"], "damage, dealing %s" % dealing)
+        assert sim.counters()["resolved"] == ref["stats"]["resolved"]
+        if dealing:
+            assert moved[0] == 0 and moved[1] > 0, moved           # no history yet -> identity; then hot arenas move
+        else:
+            assert moved == [0, 0, 0, 0]
+        finals.append(got)
+        buf.free()
+        sim.close()
+    assert np.array_equal(finals[0], finals[1])
