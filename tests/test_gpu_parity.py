@@ -752,10 +752,12 @@ def test_hot_arenas_are_dealt_evenly_and_results_do_not_change(rgp, oracle, vari
             assert np.array_equal(perm[8 * 256:], np.arange(8 * 256, B)), "the ragged last workgroup keeps its arenas"
             if dealing and nsw:
                 per_wg = np.array([np.count_nonzero(hot[perm[q * 256:(q + 1) * 256]]) for q in range(8)])
-                # 256 + 144 hot arenas in workgroups 0 and 1, average 50: each gives its 64-arena maximum per deal,
-                # the 128 go to the first open places of the workgroups below the average (50, 50, 28)
-                assert per_wg.tolist() == [192, 80, 50, 50, 28, 0, 0, 0], per_wg
-                assert nsw == 128
+                # 256 + 144 spawn-jammed arenas in workgroups 0 and 1 (nearly all of them hot by the library's count:
+                # in the event pass at >= 7/8 of the steps), q = hot / 8 per workgroup: each of the two gives its
+                # 64-arena maximum per deal, the 128 fill the open places of the following workgroups up to q
+                assert nsw == 128 and per_wg.sum() == 400, (nsw, per_wg)
+                assert per_wg[0] == 192 and per_wg[1] == 80 and 44 <= per_wg[2] == per_wg[3] <= 50, per_wg
+                assert per_wg[4] == 128 - 2 * per_wg[2] and per_wg[5:].tolist() == [0, 0, 0], per_wg
         got = sim.state()
         assert_same(got, ref["state"], "variant %d dealing %s" % (variant, dealing))
         assert_same(sim.damage().reshape(4 * n * n, B), ref["damage"], "damage, dealing %s" % dealing)
