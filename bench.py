@@ -68,8 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps-per-launch", type=int, default=0,
                     help="steps fused into one kernel launch (0 = all K: waves only re-synchronise at launch ends, so "
                          "fewer launches = less tail)")
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 wave-per-arena, 2 hybrid, 3 two-lane hybrid, 4 pooled hybrid, 5 asynchronous pooled hybrid, "
-                    "6 asynchronous pool with 32-lane groups and check-pointed fills")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 wave-per-arena, 2 hybrid, 3 two-lane hybrid, 4 pooled hybrid, 5 asynchronous pooled hybrid")
     ap.add_argument("--cpu-sample-arenas", type=int, default=2048)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg (a 1-GPU box's CPU share)")
     ap.add_argument("--cpu-seconds", type=float, default=2.5, help="target duration of each cpu_baseline leg (all threads, "

@@ -46,11 +46,8 @@ enum {
   RGS_VARIANT_HYBRID2 = 3,   /* the same with two lanes (x chains, y chains) per arena */
   RGS_VARIANT_POOL = 4,      /* HYBRID with four wavefronts per workgroup whose flagged arena-steps go through one queue in
                                 LDS: fuller event-pass rounds, wavefronts help each other, early finishers keep serving */
-  RGS_VARIANT_APOOL = 5,     /* POOL with per-arena step counts: a flagged arena's lane sits out lane passes until its step
+  RGS_VARIANT_APOOL = 5      /* POOL with per-arena step counts: a flagged arena's lane sits out lane passes until its step
                                 is back from the event pass, the rest of its wavefront goes on (bounded lag) */
-  RGS_VARIANT_APOOL_WIDE = 6 /* APOOL with 32-lane groups (n <= 3; APOOL itself above): an arena that was flagged at its last
-                                step leaves check-points of its chains during the lane pass, and the event pass fills
-                                its grid from them in up to three segments side by side */
 };
 
 /* Human-readable text for the most recent failure on this thread. */
@@ -149,9 +146,6 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * RGS_ERR_HIP until the next rgs_reset), [7] 1 if RGS_VARIANT_AUTO currently prefers the wave-per-arena
  * kernel (sustained-contact regime), else 0. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
-/* The same counters, raw: out[0..6] as above, out[7] = arena-steps whose grid the wide pool filled from check-points,
- * out[8] = the AUTO flag that rgs_get_counters reports in [7].  capacity >= 9. */
-int rgs_get_counters_ex(rgs_sim *sim, int64_t *out, int capacity);
 
 /* Diagnostic in-kernel stamps (s_memtime) of the hybrid kernels; only in a library built with
  * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable: bit 0 = stamps on

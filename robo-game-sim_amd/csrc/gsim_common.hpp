@@ -72,7 +72,6 @@ enum Counter : int {
   CNT_EVENT_STEPS = 4,    // arena-steps whose first scan found an event
   CNT_FLAGGED = 5,        // hybrid: arena-steps the lane pass handed to the wave pass
   CNT_POOL_TIMEOUT = 6,   // pooled kernel: a bounded wait ran out (protocol error; results invalid)
-  CNT_CKPT_TASKS = 7,     // wide pool: arena-steps whose grid was filled from the lane pass' check-points
   CNT_N = 8,
   // diagnostic stamps (StepArgs::stamps != 0): summed over waves, shader cycles
   STAMP_LANE = 0, STAMP_WAVE = 1, STAMP_ROUNDS = 2, STAMP_TOTAL = 3,
@@ -131,12 +130,6 @@ struct StepArgs {
   // Pooled kernels: which arena each lane slot of each workgroup steps (slot = 256 * workgroup + thread; null = the
   // arena with the slot's own index).  The host deals arenas that spent most of the last launches in the wave pass
   // evenly over the workgroups (rgs_hip.hip, rebalance): an arena's data never moves, only who computes it.
-  // Wide asynchronous pool: a lane whose arena went through the wave pass at its previous step stores its chains
-  // (positions, then velocities, chain c = 2*disc + axis) when it has integrated ckpt_col[0] and ckpt_col[1] sub-steps:
-  // ckpt[((slot * 2 + {0: p, 1: v}) * 2E + c) * B + arena].  If the arena is flagged again, the wave pass fills its grid
-  // from these check-points in up to three segments side by side (arena_step_group, SEG).  ckpt_col[1] < 0: one only.
-  double *ckpt;
-  int ckpt_col[2];
   unsigned long long *wave_log;          // diagnostic (STAMPS build, stamps on): 8 values per wavefront of the asynchronous pool
   const int *perm;
   unsigned *heat;                        // [B] arena-steps handed to the wave pass since the last deal (null: not counted)

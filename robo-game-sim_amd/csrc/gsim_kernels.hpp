@@ -153,17 +153,6 @@ constexpr int kPoolWaves = 4;                                // wavefronts per w
 constexpr int kPoolSlots = 256;                              // ring: one slot per arena of the workgroup
 constexpr int kPoolSpinLimit = 1 << 24;                      // polls of >= 64 cycles: > 0.4 s, far above any legitimate wait
 
-// Lane groups of the pooled kernels' wave pass.  WIDE (asynchronous pool, n <= 3): 32-lane groups, two arenas per round,
-// and the spare lanes fill the grid in SEG segments from the lane pass' check-points (arena_step_group); the scans
-// walk the 50 columns in two chunks instead of four.
-template <int N, bool WIDE>
-struct PoolGroups {
-  static constexpr int GW = WIDE ? 32 : HybridGroups<N>::GW;
-  static constexpr int GPW = WIDE ? 2 : HybridGroups<N>::GPW;
-  static constexpr int FIT = GW / (2 * (2 * N + 1));
-  static constexpr int SEG = !WIDE ? 1 : (FIT >= 3 ? 3 : (FIT >= 2 ? 2 : 1));
-};
-
 struct PoolQueue {                                           // lives in LDS behind the grids
   unsigned tail, head, done, pad;
   int pend[kPoolWaves];
@@ -181,10 +170,10 @@ __device__ __forceinline__ T lds_ld(const T *q) { return __hip_atomic_load(q, __
 __device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
-// payload: arena index inside the workgroup (8 bits) | step within the launch (26) | discs (16) | first column (6) | check-points (1)
+// payload: arena index inside the workgroup (8 bits) | step within the launch (26) | discs (16) | first column (6)
 __device__ __forceinline__ unsigned long long pool_pack(int local, int k, unsigned discmask) {
   return (unsigned long long)(unsigned)local | ((unsigned long long)(unsigned)k << 8) | ((unsigned long long)(discmask & 0xFFFFu) << 34) |
-         ((unsigned long long)((discmask >> 16) & 63u) << 50) | ((unsigned long long)((discmask >> 22) & 1u) << 56);
+         ((unsigned long long)((discmask >> 16) & 63u) << 50);
 }
 
 // One round: claims up to GPW tickets and runs them.  Returns the number of tickets run (0: the queue had nothing to claim).
@@ -194,13 +183,10 @@ __device__ __forceinline__ unsigned long long pool_pack(int local, int k, unsign
 #ifndef GSIM_POOL_STREAK
 #define GSIM_POOL_STREAK 2
 #endif
-#ifndef GSIM_WIDE_STREAK_EVENTS
-#define GSIM_WIDE_STREAK_EVENTS 1                            // wide pool: follow up eventful steps only (resting contact goes through the check-points)
-#endif
-template <int N, int FAST, bool ASYNC, bool WIDE = false>
+template <int N, int FAST, bool ASYNC>
 __device__ __forceinline__ int pool_round(const StepArgs &p, PoolQueue *Q, const GridView<N, false> &G, long long wg_a0, int lane,
                                            int grp, int lg) {
-  constexpr int GW = PoolGroups<N, WIDE>::GW, GPW = PoolGroups<N, WIDE>::GPW, SEG = PoolGroups<N, WIDE>::SEG;
+  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   unsigned h = 0u;
   int take = 0;
   if (lane == 0) {
@@ -237,10 +223,8 @@ __device__ __forceinline__ int pool_round(const StepArgs &p, PoolQueue *Q, const
   unsigned ev = 0u;                                          // arena_step_group's result: bit 0 events, bit 1 overlap predicates seen
   if (grp < take) {
     const int kk = (int)((payload >> 8) & 0x3FFFFFFull);
-    const unsigned dm = (unsigned)((payload >> 34) & 0xFFFFull) | ((unsigned)((payload >> 50) & 63ull) << 16) |
-                        ((unsigned)((payload >> 56) & 1ull) << 22);
-    ev = arena_step_group<N, GW, FAST, false, false, false, SEG>(p, p.ctl + (long long)kk * p.ctl_stride, (long long)Q->arena[local], G, lg,
-                                                                 lane - lg, dm);
+    const unsigned dm = (unsigned)((payload >> 34) & 0xFFFFull) | ((unsigned)((payload >> 50) & 63ull) << 16);
+    ev = arena_step_group<N, GW, FAST, false, false>(p, p.ctl + (long long)kk * p.ctl_stride, (long long)Q->arena[local], G, lg, lane - lg, dm);
   }
   wg_release();                                              // results stored before the home wavefront is told
   if (grp < take && lg == 0) {
@@ -257,8 +241,7 @@ __device__ __forceinline__ int pool_round(const StepArgs &p, PoolQueue *Q, const
       // followed up eventful steps only; the driver window's hot arenas -- pucks resting after a spawn jam -- have none.)
       // Bit 31 of the completion word tells its lane to keep waiting.  Not while trajectories are recorded:
       // the snapshot of step kk is taken by the arena's lane and must see the state of step kk.
-      const unsigned touch = (WIDE && GSIM_WIDE_STREAK_EVENTS) ? (ev & 1u) : ev;
-      const unsigned st = touch == 0u ? 0u : (Q->lastk[local] == kk - 1 ? (unsigned)Q->streak[local] + 1u : 1u);
+      const unsigned st = ev == 0u ? 0u : (Q->lastk[local] == kk - 1 ? (unsigned)Q->streak[local] + 1u : 1u);
       Q->streak[local] = (unsigned char)(st > 200u ? 200u : st);
       Q->lastk[local] = kk;
       const bool more = GSIM_POOL_STREAK > 0 && st >= (unsigned)GSIM_POOL_STREAK && p.traj == nullptr && kk + 1 < p.n_steps &&
@@ -391,11 +374,11 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_pool(StepArgs p) {
 #ifndef GSIM_POOL_FEW
 #define GSIM_POOL_FEW 4
 #endif
-template <int N, int MODE, bool WIDE = false>
+template <int N, int MODE>
 __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
-  constexpr int GW = PoolGroups<N, WIDE>::GW, GPW = PoolGroups<N, WIDE>::GPW;
+  constexpr int GW = HybridGroups<N>::GW, GPW = HybridGroups<N>::GPW;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int grp = lane / GW, lg = lane % GW;
   const long long wg_a0 = (long long)blockIdx.x * (64 * kPoolWaves);
@@ -412,7 +395,6 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
   const int K = p.n_steps;
   int kl = 0;                                                // steps this lane's arena has completed
   bool busy = false;                                         // its step kl is with the wave pass
-  bool hot_prev = false;                                     // WIDE: its previous step went through the wave pass -> store check-points
   unsigned seen_head = 0xFFFFFFFFu;
   int seen_times = 0, waits = 0;
   unsigned long long n_iter = 0, t_main = 0, n_posted = 0, n_served_arenas = 0;
@@ -449,9 +431,8 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
     if (am != 0ull && !few && !hold) {
       n_iter++;
       unsigned dm = 0u;
-      slow = active && lane_step<N, MODE, false, WIDE>(p, p.ctl + (long long)kl * p.ctl_stride, a, dm, hot_prev);
+      slow = active && lane_step<N, MODE>(p, p.ctl + (long long)kl * p.ctl_stride, a, dm);
       if (slow) discmask = dm;
-      if (active) hot_prev = slow;
       if (active && !slow) { snapshot_state<N>(p, a, kl, 0, 1); kl++; }
     }
     const bool post = slow || (few && !hold && active);
@@ -488,7 +469,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
       if (avail <= 0) { seen_times = 0; seen_head = 0xFFFFFFFFu; break; }
       if (h == seen_head) seen_times++; else { seen_head = h; seen_times = 1; }
       if (avail < GPW && can_step && seen_times < GSIM_POOL_AGE) break;
-      if (const int got = pool_round<N, FAST, true, WIDE>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; served = true; if (GSIM_STAMPS) n_served_arenas += (unsigned long long)got; }
+      if (const int got = pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; served = true; if (GSIM_STAMPS) n_served_arenas += (unsigned long long)got; }
       seen_times = 0; seen_head = 0xFFFFFFFFu;
       if (can_step) break;                                   // one round per lane pass while there are lane passes to do
     }
@@ -510,7 +491,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
   // (as in k_step_pool: a timeout here only ends this wavefront's help and is not an error)
   unsigned seen_done = 0u;
   for (int spins = 0;;) {
-    if (const int got = pool_round<N, FAST, true, WIDE>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; spins = 0; if (GSIM_STAMPS) n_served_arenas += (unsigned long long)got; continue; }
+    if (const int got = pool_round<N, FAST, true>(p, Q, G, wg_a0, lane, grp, lg)) { n_rounds++; spins = 0; if (GSIM_STAMPS) n_served_arenas += (unsigned long long)got; continue; }
     unsigned done = 0u;
     if (lane == 0) done = lds_ld(&Q->done);
     done = (unsigned)__shfl((int)done, 0);
@@ -659,8 +640,7 @@ __global__ void k_record(const double *state, const double *tcur, const double *
 
 
 // What the host needs from one n, resolved at run time through gsim_ops(n).
-enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5,
-                        LAUNCH_APOOL_WIDE = 6 };
+enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5 };
 
 struct GsimOps {
   // kind: LaunchKind; mode: DivMode (hybrids) or the wave pass division level 0/1/3 (wave kernels)
@@ -670,7 +650,6 @@ struct GsimOps {
   hipError_t (*record)(const double *state, const double *tcur, const double *damage, double *tprev, double *rec,
                        long long B, hipStream_t stream);
   size_t (*vgrid_doubles)(long long B);              // global scratch the two-lane hybrid needs (0: none)
-  int (*wide_segments)();                            // segments of the wide pool's check-pointed fill (0: no wide pool at this n)
 };
 
 }  // namespace gsim

@@ -162,12 +162,9 @@ __device__ __forceinline__ void rk4_all_chains(double *p, double *v, const doubl
 // Chains are numbered c = 2*e + axis: the puck's two chains come last (c >= 2*P).
 // Returns true when the arena must take the wave pass; discmask then holds the discs whose watch
 // fired (all discs when the division guard tripped).
-// CKPT (wide pool): when save_ckpt is set the chains are stored at the two check-point columns (StepArgs::ckpt); bit 22
-// of discmask then says that they are valid (they are not when the division guard tripped: the lane pass' arithmetic
-// is only the reference's inside the guard's window).
-template <int N, int MODE, bool COH = false, bool CKPT = false>
+template <int N, int MODE, bool COH = false>
 __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__restrict__ ctl, long long a,
-                                          unsigned &discmask, bool save_ckpt = false) {
+                                          unsigned &discmask) {
   constexpr int P = 2 * N, E = P + 1, PK = P, M = 2 * E;
   const long long B = p.B;
   const double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
@@ -318,14 +315,6 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
       for (int e = 0; e < E; ++e) any |= wd[e];
       first_col = (first_col == 0 && any) ? i + 1 : first_col;
     }
-    if (CKPT) {                                             // check-points of the arenas that were flagged last time
-      const int done = i + we;
-      if (save_ckpt && (done == p.ckpt_col[0] || done == p.ckpt_col[1])) {
-        double *dst = p.ckpt + (long long)(done == p.ckpt_col[0] ? 0 : 2 * M) * B + a;
-#pragma unroll
-        for (int c = 0; c < M; ++c) { dst[(long long)c * B] = pos[c]; dst[(long long)(M + c) * B] = vel[c]; }
-      }
-    }
   }
   if (wall_ends) {
 #pragma unroll
@@ -345,7 +334,6 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
     discmask |= wd[e] ? (1u << e) : 0u;
   }
   discmask |= (unsigned)((GSIM_LANE_HINT && first_col >= 1) ? first_col : 1) << 16;
-  if (CKPT && save_ckpt) discmask |= 1u << 22;
   if (guard) discmask = ((1u << E) - 1u) | (1u << 16);
   if (watch) return true;
 

@@ -477,20 +477,12 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // column (cpp:255-256, 287-288, 294-295 / 309, 331, 338); the puck draws nothing.  `cur` is that
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
-//
-// SEG > 1 (wide pool, SEG * 2E <= GW): bit 22 of discmask says that the lane pass left this step's chains at the
-// check-point columns p.ckpt_col[] (StepArgs::ckpt).  The fill then runs in SEG segments side by side: lane
-// (segment s, chain c) starts from the step's state (s = 0) or from check-point s - 1 and integrates up to the next
-// check-point column (the last segment to column 50).  The check-points are the lane pass' values of exactly these
-// chains at exactly these columns -- the same bits the serial chain produces (the lane pass commits its column 50 on
-// the same grounds) -- so the grid is the grid of the serial fill, in a third of the dependent sub-steps.
-template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false, bool COH = false, int SEG = 1>
+template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false, bool COH = false>
 __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
                                  const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask) {
   using L = WaveLayout<N>;
   constexpr int E = L::E, PK = L::PK;
-  static_assert(SEG * 2 * E <= GW, "group too narrow for the (segment, disc, axis) chains");
-  static_assert(SEG == 1 || (!NOISE && SEG <= 3), "segmented fill: two check-points, no noise tape");
+  static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
   const long long B = p.B;
   double TAS = gld_at<COH>(p.state, 0 * B + a, p.n_state), TBS = gld_at<COH>(p.state, 1 * B + a, p.n_state);
   if (!(TAS < p.win && TBS < p.win)) return 0u;              // undecided(), cpp:57-60,121
@@ -504,38 +496,20 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
   if (stamp) ts0 = __builtin_amdgcn_s_memtime();
 
   // ---- fill: populateStateGrid, cpp:173-217 ----
-  const bool from_ckpt = SEG > 1 && ((discmask >> 22) & 1u) != 0u;
-  const int seg = SEG > 1 ? lg / (2 * E) : 0;
-  if (lg < SEG * 2 * E && (seg == 0 || from_ckpt)) {
-    const int ch = SEG > 1 ? lg - seg * (2 * E) : lg;
-    const int e = ch >> 1, ax = ch & 1;
+  if (lg < 2 * E) {
+    const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
-    int c0 = 0, c1 = kGrid;                                  // this lane integrates columns c0+1 .. c1
-    if (from_ckpt) {
-      const int n_seg = (SEG > 2 && p.ckpt_col[1] > 0) ? 3 : 2;
-      c0 = seg == 0 ? 0 : p.ckpt_col[seg - 1];
-      c1 = seg >= n_seg - 1 ? kGrid : p.ckpt_col[seg];
-      if (seg >= n_seg) c1 = c0;                             // a third segment without a second check-point: nothing to do
-    }
     Chain x;
-    if (SEG > 1 && seg > 0) {
-      const double *src = p.ckpt + (long long)((seg - 1) * 2 * (2 * E)) * B + a;
-      x.p = src[(long long)ch * B];
-      x.v = src[(long long)(2 * E + ch) * B];
-    } else {
-      x.p = gld_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state);
-      x.v = gld_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state);
-    }
+    x.p = gld_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state);
+    x.v = gld_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state);
     double u = 0.0, coef = 0.2, tau = p.tau_puck, inv = p.inv_tau_puck;   // cpp:188: puck input is (0, 0)
     if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; inv = p.inv_tau_player; }
-    if (seg == 0) {
-      G.ctl(e, ax) = u;
-      G.pos(0, e, ax) = x.p;
-      G.vel(0, e, ax) = x.v;
-    }
+    G.ctl(e, ax) = u;
+    G.pos(0, e, ax) = x.p;
+    G.vel(0, e, ax) = x.v;
     const bool fast = FAST != 0 && fast_division_safe(u, x.v);
     const double sg = e != PK ? p.sigma : 0.0;
-    for (int i = c0 + 1; i <= c1; ++i) {
+    for (int i = 1; i <= kGrid; ++i) {
       if (NOISE) {
         const int c0 = 8 * ((i - 1) * L::P + (e != PK ? e : 0));
         x = rk4_axis_noise(x, u, coef, tau, dt_col, sg, tape + (c0 < tape_last ? c0 : tape_last) + ax);
@@ -836,7 +810,6 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
   }
   if (lg == 0) {
     if (NOISE) p.consumed[a] = cur;
-    if (SEG > 1 && from_ckpt) atomicAdd(&p.counters[CNT_CKPT_TASKS], 1ull);
     gst_at<COH>(p.tcur, a, p.n_tcur, t0 + dt);
     if (scored) { gst_at<COH>(p.state, 0 * B + a, p.n_state, TAS); gst_at<COH>(p.state, 1 * B + a, p.n_state, TBS); }
     if (had_events) {

@@ -230,7 +230,6 @@ struct rgs_sim {
   bool perm_valid = false;         // perm holds a deal (else the kernels get a null perm = identity)
   bool deal_enabled = true;        // rgs_set_rebalance
   long long heat_steps = 0;        // pooled steps counted into heat since the last deal
-  double *ckpt = nullptr;          // wide pool: the lane pass' check-points, [2][2][2E][B]
   unsigned long long *wave_log = nullptr;   // diagnostic: per-wavefront records of the asynchronous pool (stamps on)
   bool pooled_in_flight = false;   // a pooled launch has been queued since the counters were last looked at
   bool poisoned = false;
@@ -595,7 +594,6 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.sigma = 0.0; a.tape = nullptr; a.tape_off = nullptr; a.tape_n = nullptr; a.consumed = nullptr; a.vgrid = nullptr;
-  a.ckpt = nullptr; a.ckpt_col[0] = -1; a.ckpt_col[1] = -1;
   a.perm = nullptr; a.heat = nullptr; a.wave_log = s->stamps ? s->wave_log : nullptr;
   a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
   if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
@@ -673,7 +671,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   if (est_pool > best_rate) { best = RGS_VARIANT_POOL; best_rate = est_pool; }
   if (est_apool > best_rate) { best = RGS_VARIANT_APOOL; best_rate = est_apool; }
   if (est_wave > best_rate) { best = RGS_VARIANT_WAVE; best_rate = est_wave; }
-  int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : best);
+  const int variant = s->variant != RGS_VARIANT_AUTO ? s->variant : (s->auto_wave ? RGS_VARIANT_WAVE : best);
   const bool fast = use_fast_division(s);
   // The power-of-two modes fold 1/tau_player into the lane pass' step constants (gsim_lane.hpp): those
   // products must be exact and normal (or zero).
@@ -693,24 +691,12 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.vgrid = s->vgrid;
     return launch_kind(s, a, LAUNCH_HYBRID2, div_mode);
   }
-  if (variant == RGS_VARIANT_APOOL_WIDE && gsim_ops(s->n)->wide_segments() == 0) variant = RGS_VARIANT_APOOL;   // n >= 4: groups are full
-  if ((variant == RGS_VARIANT_POOL || variant == RGS_VARIANT_APOOL || variant == RGS_VARIANT_APOOL_WIDE) && n_steps < (1 << 26)) {
+  if ((variant == RGS_VARIANT_POOL || variant == RGS_VARIANT_APOOL) && n_steps < (1 << 26)) {
     RGS_TRY(rebalance(s, n_steps));
     a.perm = s->perm_valid ? s->perm : nullptr;
     a.heat = s->heat;                                          // null while dealing is off or the batch is a single workgroup
     if (s->heat) s->heat_steps += n_steps;
     s->pooled_in_flight = true;
-    if (variant == RGS_VARIANT_APOOL_WIDE) {
-      if (!s->ckpt) HIP_TRY(dev_alloc(s, &s->ckpt, sizeof(double) * 8 * (size_t)s->E * (size_t)s->B, "ckpt"));
-      // check-point columns: multiples of the pair-watch interval nearest to thirds (halves) of the 50 sub-steps
-      const int we = a.watch_every, seg = gsim_ops(s->n)->wide_segments();
-      auto up = [&](int c) { return ((c + we - 1) / we) * we; };
-      a.ckpt = s->ckpt;
-      a.ckpt_col[0] = seg >= 3 ? up(17) : up(25);
-      a.ckpt_col[1] = seg >= 3 ? up(34) : -1;
-      if (a.ckpt_col[0] >= kGrid || (seg >= 3 && (a.ckpt_col[1] >= kGrid || a.ckpt_col[1] <= a.ckpt_col[0]))) { a.ckpt_col[0] = -1; a.ckpt_col[1] = -1; }
-      return launch_kind(s, a, LAUNCH_APOOL_WIDE, div_mode);
-    }
     return launch_kind(s, a, variant == RGS_VARIANT_POOL ? LAUNCH_POOL : LAUNCH_APOOL, div_mode);
   }
   if (variant != RGS_VARIANT_WAVE) return launch_kind(s, a, LAUNCH_HYBRID, div_mode);
@@ -798,7 +784,7 @@ int rgs_destroy(rgs_sim *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
-  dev_free(s, s->ckpt); dev_free(s, s->wave_log); dev_free(s, s->perm); dev_free(s, s->heat); dev_free(s, s->hot_count); dev_free(s, s->hot_list); dev_free(s, s->cold_list); dev_free(s, s->n_swapped);
+  dev_free(s, s->wave_log); dev_free(s, s->perm); dev_free(s, s->heat); dev_free(s, s->hot_count); dev_free(s, s->hot_list); dev_free(s, s->cold_list); dev_free(s, s->n_swapped);
   dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->tapeoff_dev); dev_free(s, s->tapen_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
   if (s->counters_pin) hipHostFree(s->counters_pin);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -1053,20 +1039,6 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   return RGS_OK;
 }
 
-// The 8 device counters as they are (out[7] = arena-steps the wide pool filled from check-points), then out[8] = AUTO's
-// current preference for the wave-per-arena kernel.  capacity >= 9.
-int rgs_get_counters_ex(rgs_sim *s, int64_t *out, int capacity) {
-  if (!s || !out || capacity < 9) return fail(RGS_ERR_ARG, "rgs_get_counters_ex: bad argument");
-  HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipMemcpyAsync(out, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  s->pooled_in_flight = false;
-  if (out[CNT_POOL_TIMEOUT] != 0) s->poisoned = true;
-  out[8] = s->auto_wave ? 1 : 0;
-  if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
-  return RGS_OK;
-}
-
 // Diagnostic: per-phase shader-cycle totals of the hybrid kernels since the last reset (or clear).
 // enable: bit 0 = stamps on for later launches, bit 1 = clear the totals first.  out: min(capacity, STAMP_N = 17) values.
 int rgs_get_stamps(rgs_sim *s, int enable, int64_t *out, int capacity) {
@@ -1135,7 +1107,7 @@ int rgs_debug_inject_pool_timeout(rgs_sim *s) {
 }
 
 int rgs_set_variant(rgs_sim *s, int variant) {
-  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_APOOL_WIDE) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
+  if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_APOOL) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
   return RGS_OK;
 }

@@ -24,13 +24,11 @@ hipError_t launch_hybrid_mode(const StepArgs &args, hipStream_t stream) {
   return hipGetLastError();
 }
 
-constexpr bool kHasWide = PoolGroups<N, true>::SEG > 1;        // the wide pool exists where a 32-lane group has spare lanes (n <= 3)
-
-template <int MODE, bool ASYNC, bool WIDE = false>
+template <int MODE, bool ASYNC>
 hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + 64 * kPoolWaves - 1) / (64 * kPoolWaves);
-  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * PoolGroups<N, WIDE>::GPW * kPoolWaves + sizeof(PoolQueue);
-  const void *fn = WIDE ? (const void *)k_step_apool<N, MODE, WIDE> : ASYNC ? (const void *)k_step_apool<N, MODE> : (const void *)k_step_pool<N, MODE>;
+  const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW * kPoolWaves + sizeof(PoolQueue);
+  const void *fn = ASYNC ? (const void *)k_step_apool<N, MODE> : (const void *)k_step_pool<N, MODE>;
   // > 64 KB of dynamic LDS has to be asked for once per instantiation AND per device (the attribute belongs to the
   // device's function object); one bit per device, set after the call succeeded -- a second thread racing here at
   // worst repeats the (idempotent) call.
@@ -44,8 +42,7 @@ hipError_t launch_pool_mode(const StepArgs &args, hipStream_t stream) {
     if (e != hipSuccess) return e;
     if (dev < 64) attr_set.fetch_or(bit, std::memory_order_release);
   }
-  if (WIDE) hipLaunchKernelGGL((k_step_apool<N, MODE, WIDE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
-  else if (ASYNC) hipLaunchKernelGGL((k_step_apool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
+  if (ASYNC) hipLaunchKernelGGL((k_step_apool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
   else hipLaunchKernelGGL((k_step_pool<N, MODE>), dim3((unsigned)blocks), dim3(64 * kPoolWaves), lds, stream, args);
   return hipGetLastError();
 }
@@ -89,13 +86,6 @@ hipError_t step(const StepArgs &args, hipStream_t stream, int kind, int mode) {
              : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2, true>(args, stream)
              : mode == DIV_MARKSTEIN ? launch_pool_mode<DIV_MARKSTEIN, true>(args, stream)
                                      : launch_pool_mode<DIV_IEEE, true>(args, stream);
-    case LAUNCH_APOOL_WIDE:
-      if constexpr (kHasWide)
-        return mode == DIV_POW2_ONESTEP ? launch_pool_mode<DIV_POW2_ONESTEP, true, true>(args, stream)
-               : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2, true, true>(args, stream)
-               : mode == DIV_MARKSTEIN ? launch_pool_mode<DIV_MARKSTEIN, true, true>(args, stream)
-                                       : launch_pool_mode<DIV_IEEE, true, true>(args, stream);
-      return hipErrorInvalidValue;
     case LAUNCH_HYBRID2:
       return mode == DIV_POW2_ONESTEP ? launch_hybrid2_mode<DIV_POW2_ONESTEP>(args, stream)
              : mode == DIV_PLAYER_POW2 ? launch_hybrid2_mode<DIV_PLAYER_POW2>(args, stream)
@@ -128,11 +118,7 @@ size_t vgrid_doubles(long long B) {
   return (size_t)blocks * HybridGroups<N, SPLITV, Hybrid2Split<N>::LDS_KB>::GPW * GridView<N, SPLITV>::GV_DOUBLES;
 }
 
-// Wide pool: check-point columns for a pair-watch interval `we` (they must be multiples of it) and the doubles of the
-// check-point buffer per arena; segments = 0: this team size has no wide pool.
-int wide_segments() { return kHasWide ? PoolGroups<N, true>::SEG : 0; }
-
-const GsimOps kOps = {step, reset, record, vgrid_doubles, wide_segments};
+const GsimOps kOps = {step, reset, record, vgrid_doubles};
 
 }  // namespace
 

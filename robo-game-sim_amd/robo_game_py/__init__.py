@@ -17,7 +17,7 @@ import struct
 import numpy as np
 
 from . import _lib
-from ._lib import RgsError, VARIANT_APOOL, VARIANT_APOOL_WIDE, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_WAVE  # noqa: F401
+from ._lib import RgsError, VARIANT_APOOL, VARIANT_AUTO, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_WAVE  # noqa: F401
 
 __all__ = ["GameSim", "BatchedGameSim", "SimStateView", "RgsError", "reset_arguments", "state_size",
            "log_record"]
@@ -341,12 +341,11 @@ class BatchedGameSim:
             _lib.check(self._L.rgs_set_damage(self._h, _lib.dptr(d)))
 
     def counters(self):
-        out = (C.c_int64 * 9)()
-        _lib.check(self._L.rgs_get_counters_ex(self._h, out, 9))
+        out = (C.c_int64 * 8)()
+        _lib.check(self._L.rgs_get_counters(self._h, out))
         names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps", "flagged"]
         d = dict(zip(names, list(out)[:6]))
-        d["filled_from_checkpoints"] = int(out[7])
-        d["auto_prefers_wave"] = int(out[8])
+        d["auto_prefers_wave"] = int(out[7])
         return d
 
     def stamps(self, enable=True, clear=False):

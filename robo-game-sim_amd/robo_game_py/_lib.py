@@ -18,7 +18,7 @@ RGS_ERR_HIP = -2
 RGS_ERR_UNSUPPORTED = -3
 RGS_ERR_NO_DEVICE = -4
 
-VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_APOOL, VARIANT_APOOL_WIDE = 0, 1, 2, 3, 4, 5, 6
+VARIANT_AUTO, VARIANT_WAVE, VARIANT_HYBRID, VARIANT_HYBRID2, VARIANT_POOL, VARIANT_APOOL = 0, 1, 2, 3, 4, 5
 
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
@@ -56,7 +56,6 @@ SIGNATURES = {
     "rgs_timer_start": (C.c_int, [_vp]),
     "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
-    "rgs_get_counters_ex": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int]),
     "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "rgs_debug_check_guards": (C.c_int, [_vp]),
     "rgs_debug_wave_log": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int64]),

@@ -69,7 +69,7 @@ def test_gpu_matches_reference_samples(rgp, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6], ids=["wave", "hybrid", "hybrid2", "pool", "apool", "apool_wide"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5], ids=["wave", "hybrid", "hybrid2", "pool", "apool"])
 @pytest.mark.parametrize("path", NPZ, ids=[os.path.basename(p)[:-4] for p in NPZ])
 def test_gpu_reproduces_golden(rgp, path, variant):
     g = np.load(path)

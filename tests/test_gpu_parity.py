@@ -253,8 +253,7 @@ def test_c1_run_sim_loop_100_seconds(rgp, oracle):
     assert g.time() == o.time() and g.undecided() == o.undecided()
 
 
-VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid"), pytest.param(3, id="hybrid2"), pytest.param(4, id="pool"), pytest.param(5, id="apool"),
-            pytest.param(6, id="apool_wide")]
+VARIANTS = [pytest.param(1, id="wave"), pytest.param(2, id="hybrid"), pytest.param(3, id="hybrid2"), pytest.param(4, id="pool"), pytest.param(5, id="apool")]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -465,7 +464,7 @@ def test_parameter_fuzz(rgp, oracle, seed):
         sim.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_pathological_inputs_neither_hang_nor_diverge(rgp, oracle, variant):
     """NaN / inf / 1e200 controls and states, dt = 0, a tiny tau: every loop of the kernels is bounded
     and every grid index clamped, so the step returns, and what it returns equals the oracle's result
@@ -493,7 +492,7 @@ def test_pathological_inputs_neither_hang_nor_diverge(rgp, oracle, variant):
                                                                       sorted(set(np.argwhere(~same)[:, 1].tolist()))[:10])
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n", [2, 4])
 def test_in_kernel_trajectory_snapshots(rgp, oracle, n, variant):
     """State snapshots taken inside one fused launch equal the oracle's recorded trajectory."""
@@ -566,7 +565,7 @@ def oracle_from_state(oracle, n, st, table, dt, win=3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_division_guard_on_one_axis_only(rgp, oracle, variant):
     """A control far below the fast-division window on ONE axis trips the guard in one lane of the
     two-lane pass only; the arena must still be re-run from column 1 (an early wall bounce of another
@@ -663,7 +662,7 @@ def test_every_kernel_instantiation_matches_oracle(rgp, oracle, n):
         ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, want_damage=True,
                                tau_puck=tau_puck, tau_player=tau_player)
         assert ref["stats"]["resolved"] > 50
-        for variant in (1, 2, 3, 4, 5, 6):
+        for variant in (1, 2, 3, 4, 5):
             sim = rgp.BatchedGameSim(B, n)
             sim.set_variant(variant)
             sim.set_fast_division(level)
@@ -676,7 +675,7 @@ def test_every_kernel_instantiation_matches_oracle(rgp, oracle, n):
             sim.close()
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6], ids=["pool", "apool", "apool_wide"])
+@pytest.mark.parametrize("variant", [4, 5], ids=["pool", "apool"])
 @pytest.mark.parametrize("B", [1, 3, 63, 257, 1000])
 def test_pooled_kernels_on_ragged_batches(rgp, oracle, variant, B):
     """The pooled kernels own 256 arenas per workgroup: batches that leave wavefronts partly or wholly empty, a
@@ -719,7 +718,7 @@ def test_pool_timeout_is_a_sticky_error_until_reset(rgp):
     sim.close()
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6], ids=["pool", "apool", "apool_wide"])
+@pytest.mark.parametrize("variant", [4, 5], ids=["pool", "apool"])
 def test_hot_arenas_are_dealt_evenly_and_results_do_not_change(rgp, oracle, variant):
     """Pooled kernels: arenas in lasting contact (here: pucks spawned inside a player, all of them in the first two
     workgroups) are dealt over the workgroups between fused launches.  The deal must be a permutation that evens out
@@ -771,28 +770,3 @@ def test_hot_arenas_are_dealt_evenly_and_results_do_not_change(rgp, oracle, vari
         buf.free()
         sim.close()
     assert np.array_equal(finals[0], finals[1])
-
-
-@pytest.mark.parametrize("n,dt,watch", [(2, 0.01, 1), (2, 0.01, 5), (2, 0.05, 1), (2, 0.01, 10), (1, 0.01, 1), (3, 0.01, 1), (3, 0.05, 1), (2, 0.01, 0)])
-def test_wide_pool_fills_from_checkpoints(rgp, oracle, n, dt, watch):
-    """Variant 6: arenas flagged at consecutive steps have their grids filled from the lane pass' check-points (three
-    segments at 1v1 / 2v2, two at 3v3), at every pair-watch interval (the check-point columns are multiples of it).
-    Contact-rich play: pucks spawned against players, circle commands.  Bits as the oracle's, and the counter shows
-    that the segmented fill really ran."""
-    from robo_game_py import workloads as w
-    B, K = 700, 60
-    x0, amp, ph = w.c2_inputs(B, n, seed=900 + n)
-    x0[:, ::3] = np.array([[-2.5 + 0.3], [5.0 / 2 - 5.0 / (2 * n) + 0.1], [0.0], [0.0]])   # every third puck rests against A1
-    table = w.circle_controls(amp * 1.5, ph, w.step_times(K, dt))
-    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, want_damage=True)
-    sim = rgp.BatchedGameSim(B, n)
-    sim.set_variant(6)
-    sim.set_sparse_watch(watch)
-    sim.reset(dt, 1000, x0)
-    got = sim.run_table(table, chunk_steps=K)
-    c = sim.counters()
-    assert_same(got, ref["state"], "wide pool n=%d dt=%g watch=%d" % (n, dt, watch))
-    assert_same(sim.damage().reshape(4 * n * n, B), ref["damage"], "damage")
-    assert c["resolved"] == ref["stats"]["resolved"] and c["cap_hits"] == ref["stats"]["cap_hits"]
-    assert c["filled_from_checkpoints"] > 50, c
-    sim.close()
