@@ -92,7 +92,8 @@ int rgs_step_device_traj(rgs_sim *sim, const double *controls_dev, int64_t step_
  * include/utils.h:64-76).  rec_dev: [n_steps][R][B] doubles on the device, R =
  * rgs_record_size(n) = 3 + 2 + 2P + P*P + 1: t, TAS, TBS, puck xy, players' xy, the P damage blocks in
  * the reference's byte order, and a final "executed" row (1.0 where the step really ran; the
- * reference writes no record for a decided game).  One step + one record kernel per step. */
+ * reference writes no record for a decided game).  One fused launch: the records are written inside the stepping kernel
+ * after each step (round 2: one step launch + one record launch per step). */
 int rgs_record_size(int n_per_team);
 int rgs_step_device_record(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps,
                            double *rec_dev);

@@ -122,6 +122,11 @@ struct StepArgs {
   // k % traj_every == 0 the state of every arena is copied to traj[(k/traj_every - 1)][S][B]
   double *traj;
   int traj_every;
+  // the reference's log record of EVERY step of the launch (src/GameSim.cpp:161-170, include/utils.h:64-76), written by
+  // the same lanes at the same point as the snapshots: rec[k][R][B], R = 3 + 2 + 2P + P*P + 1 (see snapshot_state);
+  // tprev[B] = t_ of every arena when the launch began (for the "executed" row of the launch's first step).
+  double *rec;
+  const double *tprev;
   double *vgrid;                     // two-lane hybrid, n >= 4: velocity rows of the grids (GridView<N, true>)
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
@@ -288,12 +293,37 @@ __device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, 
 
 // Snapshot of arena a's state rows into the trajectory buffer (see StepArgs::traj).  Called by the
 // `nl` lanes that own the arena after its step k0 (0-based) is complete and visible.
+//
+// With StepArgs::rec the same lanes also write the reference's log record of the step (cpp:161-170): rows t, TAS, TBS,
+// puck x y, every player's x y, then the P "damage.row(k)" blocks exactly as the reference's logVectors writes them -- P
+// contiguous doubles starting at flat COLUMN-MAJOR element k (utils.h:75 takes row(k).data() of a column-major Matrix and
+// writes rows*cols doubles from there), i.e. block k, entry q = damage(row (k+q) % P, column (k+q) / P) -- and a last row
+// "executed": 1.0 if this step advanced the arena's clock (a decided game logs nothing, cpp:121-123), judged against the
+// previous record of the launch (the launch's first step: against StepArgs::tprev).
+__device__ __forceinline__ bool recording(const StepArgs &p) { return p.traj != nullptr || p.rec != nullptr; }
+
 template <int N, bool COH = false>
 __device__ __forceinline__ void snapshot_state(const StepArgs &p, long long a, int k0, int lane, int nl) {
+  constexpr int P = 2 * N, S = 2 + 4 * (P + 1), R = 3 + 2 + 2 * P + P * P + 1;
+  const long long B = p.B;
+  if (p.rec != nullptr) {
+    double *dst = p.rec + (long long)k0 * R * B;
+    for (int r = lane; r < R; r += nl) {
+      double v;
+      if (r == 0) v = gld_at<COH>(p.tcur, a, p.n_tcur);
+      else if (r < 5) v = gld_at<COH>(p.state, (long long)(r - 1) * B + a, p.n_state);               // TAS, TBS, puck x, y
+      else if (r < 5 + 2 * P) { const int e = (r - 5) >> 1, ax = (r - 5) & 1; v = gld_at<COH>(p.state, (long long)(6 + 4 * e + ax) * B + a, p.n_state); }
+      else if (r < R - 1) { const int flat = (r - 5 - 2 * P) / P + (r - 5 - 2 * P) % P; v = gld_at<COH>(p.damage, (long long)((flat % P) * P + flat / P) * B + a, p.n_damage); }
+      else {
+        const double before = k0 == 0 ? p.tprev[a] : (p.rec + (long long)(k0 - 1) * R * B)[a];
+        v = gld_at<COH>(p.tcur, a, p.n_tcur) != before ? 1.0 : 0.0;
+      }
+      dst[(long long)r * B + a] = v;
+    }
+  }
   if (p.traj == nullptr || (k0 + 1) % p.traj_every != 0) return;
-  constexpr int S = 2 + 4 * (2 * N + 1);
-  double *dst = p.traj + (long long)((k0 + 1) / p.traj_every - 1) * S * p.B;
-  for (int r = lane; r < S; r += nl) dst[(long long)r * p.B + a] = gld_at<COH>(p.state, (long long)r * p.B + a, p.n_state);
+  double *dst = p.traj + (long long)((k0 + 1) / p.traj_every - 1) * S * B;
+  for (int r = lane; r < S; r += nl) dst[(long long)r * B + a] = gld_at<COH>(p.state, (long long)r * B + a, p.n_state);
 }
 
 // Orders LDS traffic between lanes of ONE wavefront: LDS operations of a wave

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
   const GridView<N, false> G{lds + (wave * GPW + grp) * L::DOUBLES, nullptr GSIM_GRID_DBG(p)};
   for (int k = 0; k < p.n_steps; ++k) {
     arena_step_group<N, GW, FAST, NOISE, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
-    if (p.traj != nullptr) {
+    if (recording(p)) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the commit's stores, then the copy's loads
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       snapshot_state<N>(p, a, k, lg, GW);
@@ -244,7 +244,7 @@ __device__ __forceinline__ int pool_round(const StepArgs &p, PoolQueue *Q, const
       const unsigned st = ev == 0u ? 0u : (Q->lastk[local] == kk - 1 ? (unsigned)Q->streak[local] + 1u : 1u);
       Q->streak[local] = (unsigned char)(st > 200u ? 200u : st);
       Q->lastk[local] = kk;
-      const bool more = GSIM_POOL_STREAK > 0 && st >= (unsigned)GSIM_POOL_STREAK && p.traj == nullptr && kk + 1 < p.n_steps &&
+      const bool more = GSIM_POOL_STREAK > 0 && st >= (unsigned)GSIM_POOL_STREAK && !recording(p) && kk + 1 < p.n_steps &&
                         kk + 1 <= lds_ld(&Q->front[local >> 6]) + 1;
       if (more) {
         const unsigned tk = __hip_atomic_fetch_add(&Q->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
     unsigned discmask = 0xFFFFu | (1u << 16);                // a step posted without a lane pass: every disc, from column 1
     bool slow = false;
     // a lane pass costs the same for one arena as for 64: the last few stragglers go through the wave pass
-    const bool few = p.traj == nullptr && __builtin_popcountll(am) <= GSIM_POOL_FEW;
+    const bool few = !recording(p) && __builtin_popcountll(am) <= GSIM_POOL_FEW;
     if (am != 0ull && !few && !hold) {
       n_iter++;
       unsigned dm = 0u;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64 * kPoolWaves, 1) void k_step_apool(StepArgs p) {
     if (GSIM_STAMPS && p.stamps) { t1 = __builtin_amdgcn_s_memtime(); t_lane += t1 - t0; }
     // serve: a full round, or a task that has been seen waiting before, or anything at all when this
     // wavefront cannot take a lane pass now
-    const bool can_step = !hold && __builtin_popcountll(__ballot(mine && !busy && kl < K)) > (p.traj == nullptr ? GSIM_POOL_FEW : 0);
+    const bool can_step = !hold && __builtin_popcountll(__ballot(mine && !busy && kl < K)) > (!recording(p) ? GSIM_POOL_FEW : 0);
     bool served = false;
     for (;;) {
       unsigned h = 0u;
@@ -608,37 +608,6 @@ __global__ void k_reset(double *state, double *tcur, double *damage, const doubl
   (void)E;
 }
 
-// One log record per arena (src/GameSim.cpp:161-170, include/utils.h:64-76), SoA: rec[R][B] with
-// R = 3 + 2 + 2P + P*P + 1: t, TAS, TBS, puck xy, players' xy, the P "damage.row(k)" blocks exactly as
-// the reference writes them (P contiguous doubles starting at flat column-major element k), and a
-// last row "executed" (1.0 if this step advanced the arena: a decided game logs nothing, cpp:121).
-template <int N>
-__global__ void k_record(const double *state, const double *tcur, const double *damage, double *tprev,
-                         double *rec, long long B) {
-  constexpr int P = 2 * N;
-  const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= B) return;
-  int r = 0;
-  const double t = tcur[a];
-  rec[(long long)(r++) * B + a] = t;
-  rec[(long long)(r++) * B + a] = state[0 * B + a];
-  rec[(long long)(r++) * B + a] = state[1 * B + a];
-  rec[(long long)(r++) * B + a] = state[2 * B + a];
-  rec[(long long)(r++) * B + a] = state[3 * B + a];
-  for (int e = 0; e < P; ++e) {
-    rec[(long long)(r++) * B + a] = state[(long long)(6 + 4 * e) * B + a];
-    rec[(long long)(r++) * B + a] = state[(long long)(7 + 4 * e) * B + a];
-  }
-  for (int k = 0; k < P; ++k)
-    for (int q = 0; q < P; ++q) {
-      const int flat = k + q;                         // column-major flat index: row = flat % P, col = flat / P
-      rec[(long long)(r++) * B + a] = damage[(long long)((flat % P) * P + flat / P) * B + a];
-    }
-  rec[(long long)(r++) * B + a] = (t != tprev[a]) ? 1.0 : 0.0;
-  tprev[a] = t;
-}
-
-
 // What the host needs from one n, resolved at run time through gsim_ops(n).
 enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5 };
 
@@ -647,8 +616,6 @@ struct GsimOps {
   hipError_t (*step)(const StepArgs &args, hipStream_t stream, int kind, int mode);
   hipError_t (*reset)(double *state, double *tcur, double *damage, const double *x0, int x0_batched, long long B,
                       hipStream_t stream);
-  hipError_t (*record)(const double *state, const double *tcur, const double *damage, double *tprev, double *rec,
-                       long long B, hipStream_t stream);
   size_t (*vgrid_doubles)(long long B);              // global scratch the two-lane hybrid needs (0: none)
 };
 

@@ -552,7 +552,7 @@ int rebalance(rgs_sim *s, int n_steps) {
 }
 
 int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_steps, double *traj = nullptr,
-                 int traj_every = 0) {
+                 int traj_every = 0, double *rec = nullptr) {
   StepArgs a{};
   a.dt = s->dt; a.dt_col = s->dt_col;
   a.tau_player = s->tau_player; a.tau_puck = s->tau_puck;
@@ -596,6 +596,7 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.sigma = 0.0; a.tape = nullptr; a.tape_off = nullptr; a.tape_n = nullptr; a.consumed = nullptr; a.vgrid = nullptr;
   a.perm = nullptr; a.heat = nullptr; a.wave_log = s->stamps ? s->wave_log : nullptr;
   a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
+  a.rec = rec; a.tprev = s->tprev;
   if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
@@ -604,8 +605,10 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
       StepArgs b = a;
       b.traj = snap ? traj + (long long)((k + 1) / a.traj_every - 1) * s->S * s->B : nullptr;
       b.traj_every = 1;
+      b.rec = rec ? rec + (long long)k * rgs_record_size(s->n) * s->B : nullptr;   // one step per launch: record index 0, tprev kept current
       int rc = noise_step(s, b);
       if (rc != RGS_OK) return rc;
+      if (rec) HIP_TRY(hipMemcpyAsync(s->tprev, s->tcur, sizeof(double) * s->B, hipMemcpyDeviceToDevice, s->stream));
     }
     return RGS_OK;
   }
@@ -860,18 +863,11 @@ int rgs_record_size(int n_per_team) { return 3 + 2 + 4 * n_per_team + 4 * n_per_
 int rgs_step_device_record(rgs_sim *s, const double *controls_dev, int64_t step_stride, int n_steps, double *rec_dev) {
   if (!s || !controls_dev || !rec_dev || n_steps < 0 || step_stride < 0) return fail(RGS_ERR_ARG, "rgs_step_device_record: bad argument");
   HIP_TRY(hipSetDevice(s->device));
-  const int R = rgs_record_size(s->n);
-  const int tb = 256;
-  const dim3 grid((unsigned)((s->B + tb - 1) / tb));
+  if (n_steps == 0) return RGS_OK;
+  // ONE fused launch: every kernel writes the record of each step right after the step, in the kernel (snapshot_state,
+  // gsim_common.hpp).  tprev = the clocks before the launch, for the "executed" row of its first step.
   HIP_TRY(hipMemcpyAsync(s->tprev, s->tcur, sizeof(double) * s->B, hipMemcpyDeviceToDevice, s->stream));
-  for (int k = 0; k < n_steps; ++k) {
-    int rc = launch_steps(s, controls_dev + (long long)k * step_stride, 0, 1);
-    if (rc != RGS_OK) return rc;
-    double *rec = rec_dev + (long long)k * R * s->B;
-    HIP_TRY(gsim_ops(s->n)->record(s->state, s->tcur, s->damage, s->tprev, rec, s->B, s->stream));
-    HIP_TRY(hipGetLastError());
-  }
-  return RGS_OK;
+  return launch_steps(s, controls_dev, step_stride, n_steps, nullptr, 0, rec_dev);
 }
 
 int rgs_sync(rgs_sim *s) {

@@ -103,14 +103,6 @@ hipError_t reset(double *state, double *tcur, double *damage, const double *x0, 
   return hipGetLastError();
 }
 
-hipError_t record(const double *state, const double *tcur, const double *damage, double *tprev, double *rec,
-                  long long B, hipStream_t stream) {
-  const int tb = 256;
-  hipLaunchKernelGGL((k_record<N>), dim3((unsigned)((B + tb - 1) / tb)), dim3(tb), 0, stream, state, tcur, damage,
-                     tprev, rec, B);
-  return hipGetLastError();
-}
-
 size_t vgrid_doubles(long long B) {
   constexpr bool SPLITV = Hybrid2Split<N>::value;
   if (!SPLITV) return 0;
@@ -118,7 +110,7 @@ size_t vgrid_doubles(long long B) {
   return (size_t)blocks * HybridGroups<N, SPLITV, Hybrid2Split<N>::LDS_KB>::GPW * GridView<N, SPLITV>::GV_DOUBLES;
 }
 
-const GsimOps kOps = {step, reset, record, vgrid_doubles};
+const GsimOps kOps = {step, reset, vgrid_doubles};
 
 }  // namespace
 

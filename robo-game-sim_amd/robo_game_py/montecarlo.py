@@ -85,16 +85,25 @@ def mindless_policy(state, k, t, seeds):
     return u
 
 
+# A policy whose commands do not depend on the state's VALUES (only on k, t, seeds and the array shapes) may say so:
+# monte_carlo_batched then asks it for a whole chunk of steps at once and runs the chunk as ONE fused launch, log
+# records included (the stepping kernels write them in-kernel), instead of one launch and one download per step.
+mindless_policy.open_loop = True
+
+
 NOISE_MAX_ARENAS = 4096      # include/rgs_hip.h: noise != 0 needs host-generated draw tapes, <= 4096 arenas per handle
 
 
 def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=0, write_logs=True, logged_runs=None,
-                        sim=None, _first_run=1, _write_config=True):
+                        sim=None, _first_run=1, _write_config=True, chunk_steps=64):
     """All runs of the ensemble at once.
 
     policy(state (S, B), k, t, seeds (B,)) -> controls (P, 2, B); called once per step for the whole batch
     (k = step index, t = k*dt accumulated like py/run_sim.py:75).  logged_runs: iterable of 1-based run
     numbers whose mc_run_<i>.log to write (default: all when write_logs).
+    A policy marked `open_loop = True` (its commands ignore the state's values: mindless_policy) is evaluated for
+    chunk_steps steps ahead and each chunk runs as one fused launch, log records included; any other policy is closed
+    loop: one step, one state download per step, like the reference (py/MonteCarlo.py:36-45).
     With noise_stdev != 0 an ensemble of more than 4096 runs is stepped in chunks of 4096 (one handle each,
     the stepper's limit for host-generated noise tapes); run i keeps seed i either way.
     Returns dict(state (S, B), scores (2, B), damage (P, P, B), undecided (B,), steps).
@@ -109,7 +118,7 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
             sub = copy.copy(mc_params)
             sub.num_runs = min(NOISE_MAX_ARENAS, B - lo)
             parts.append(monte_carlo_batched(sub, policy, n_per_team, device, write_logs, logged_runs, None,
-                                             _first_run=_first_run + lo, _write_config=False))
+                                             _first_run=_first_run + lo, _write_config=False, chunk_steps=chunk_steps))
         return dict(state=np.concatenate([q["state"] for q in parts], axis=1),
                     scores=np.concatenate([q["scores"] for q in parts], axis=1),
                     damage=np.concatenate([q["damage"] for q in parts], axis=2),
@@ -133,22 +142,37 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
             files[r] = open(os.path.join(mc_params.log_prefix, "mc_run_{}.log".format(r)), "wb")
     R = sim.record_size()
 
-    def step(controls):
-        if files:
-            rec = sim.run_table_recorded(controls[None])[0]                 # (R, B)
-            for r, f in files.items():
-                if rec[R - 1, r - _first_run] != 0.0:                       # a decided game logs nothing
-                    f.write(rec[:R - 1, r - _first_run].tobytes())
-            return None
-        sim.step(controls)
-        return None
+    cols = np.array([r - _first_run for r in files], dtype=np.int64)
+    handles = list(files.values())
 
-    step(np.zeros((P, 2, B)))                                               # py/MonteCarlo.py:33
+    def run(table):                                                         # table (K, P, 2, B): K steps, logged if asked for
+        if files:
+            rec = sim.run_table_recorded(table, chunk_steps=max(1, chunk_steps))      # (K, R, B): fused launches
+            per_run = np.ascontiguousarray(rec[:, :, cols].transpose(2, 0, 1))        # (n_logged, K, R): one pass over the chunk
+            ran = per_run[:, :, R - 1] != 0.0                               # a decided game logs nothing (cpp:121-123)
+            for q, f in enumerate(handles):
+                f.write(per_run[q, ran[q], :R - 1].tobytes())
+        elif len(table) == 1:
+            sim.step(table[0])
+        else:
+            sim.run_table(table, chunk_steps=max(1, chunk_steps))
+
+    run(np.zeros((1, P, 2, B)))                                             # py/MonteCarlo.py:33
     t = 0.0
-    for k in range(N):
-        state = sim.state()
-        step(np.ascontiguousarray(policy(state, k, t, seeds), dtype=np.float64))
-        t += mc_params.dt
+    if getattr(policy, "open_loop", False):
+        state = sim.state()                                                 # shapes only; an open-loop policy ignores the values
+        for k0 in range(0, N, max(1, chunk_steps)):
+            k1 = min(N, k0 + max(1, chunk_steps))
+            table = np.empty((k1 - k0, P, 2, B))
+            for k in range(k0, k1):
+                table[k - k0] = policy(state, k, t, seeds)
+                t += mc_params.dt
+            run(table)
+    else:
+        for k in range(N):
+            state = sim.state()
+            run(np.ascontiguousarray(policy(state, k, t, seeds), dtype=np.float64)[None])
+            t += mc_params.dt
     for f in files.values():
         f.close()
     state = sim.state()

@@ -97,19 +97,26 @@ def test_batched_monte_carlo_equals_sequential(rgp, oracle, tmp_path):
     assert out["scores"].sum() > 0 and (~out["undecided"]).any()       # some games were decided early
 
 
-def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path):
-    """run_table_recorded returns exactly the reference's per-step record for every arena (4v4 too)."""
+@pytest.mark.parametrize("variant,chunk", [(0, 64), (1, 64), (2, 64), (3, 64), (4, 64), (5, 64), (5, 7), (2, 1)])
+def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path, variant, chunk):
+    """run_table_recorded returns exactly the reference's per-step record for every arena (4v4 too).  The records are
+    written inside the fused stepping launch by every kernel variant; chunk = steps per launch (7: the "executed" row of a
+    launch's first step is judged against the clocks the previous launch left; 1: the old one-launch-per-step shape)."""
     from robo_game_py import workloads as w
     for n in (2, 4):
-        B, K = 6, 60
+        B, K, checked = 300, 60, 8
         x0, _, _ = w.c2_inputs(B, n, seed=8)
         table = w.random_hold_controls(2 * n, B, K, 10.0, hold=10, seed=n)
         sim = rgp.BatchedGameSim(B, n)
+        sim.set_variant(variant)
         sim.reset(0.05, 1, x0)
-        rec = sim.run_table_recorded(table)
+        rec = sim.run_table_recorded(table, chunk_steps=chunk)
         R = sim.record_size()
         assert rec.shape == (K, R, B) and R == 3 + 2 + 4 * n + 4 * n * n + 1
-        for a in range(B):
+        ref = oracle.batch_run(n, x0, table, K, dt=0.05, winning_score=1, n_threads=8)
+        assert np.array_equal(sim.state(), ref["state"])
+        decided_early = 0
+        for a in list(range(checked)) + [B - 1]:
             path = str(tmp_path / ("n%d_a%d.log" % (n, a)))
             o = oracle.OracleGameSim(n)
             o.reset(0.05, 1, x0[:, a], 0.0, True, path)
@@ -120,7 +127,35 @@ def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path):
             ran = rec[:, R - 1, a] != 0.0
             assert ran.sum() == len(want)
             assert np.array_equal(rec[ran, :R - 1, a], want)
+            decided_early += len(want) < K
+        # every arena: the executed row is exactly "the clock moved", and decided games stop logging for good
+        t = rec[:, 0, :]
+        moved = np.diff(np.concatenate([np.zeros((1, B)), t]), axis=0) != 0.0
+        assert np.array_equal(moved, rec[:, R - 1, :] != 0.0)
         sim.close()
+
+
+def test_recorded_steps_with_noise(rgp, oracle, tmp_path):
+    """noise > 0 (host-tape wave kernel, one step per launch): the in-kernel records still equal the reference's log."""
+    from robo_game_py import workloads as w
+    n, B, K = 2, 12, 40
+    x0, _, _ = w.c2_inputs(B, n, seed=18)
+    table = w.random_hold_controls(2 * n, B, K, 8.0, hold=8, seed=5)
+    sim = rgp.BatchedGameSim(B, n)
+    sim.reset(0.05, 2, x0, 0.3, False, "", 11)
+    rec = sim.run_table_recorded(table, chunk_steps=16)
+    R = sim.record_size()
+    for a in range(B):
+        path = str(tmp_path / ("noise_a%d.log" % a))
+        o = oracle.OracleGameSim(n)
+        o.reset(0.05, 2, x0[:, a], 0.3, True, path, 11 + a)
+        for k in range(K):
+            o.run(np.ascontiguousarray(table[k, :, :, a]))
+        o.reset(0.05, 2, x0[:, a])
+        want = np.frombuffer(open(path, "rb").read(), dtype=np.float64).reshape(-1, R - 1)
+        ran = rec[:, R - 1, a] != 0.0
+        assert ran.sum() == len(want) and np.array_equal(rec[ran, :R - 1, a], want)
+    sim.close()
 
 
 def test_closed_loop_on_device_matches_host_loop(rgp, oracle):
