@@ -175,6 +175,19 @@ int rgs_debug_inject_pool_timeout(rgs_sim *sim);
 
 int rgs_set_variant(rgs_sim *sim, int variant);
 
+/* noise != 0 (w_stdev_, src/GameSim.cpp:30,66-67), two modes, chosen BEFORE rgs_reset:
+ *   0 (default) exact: the draws come from the reference's own std::default_random_engine / std::normal_distribution
+ *     on the host (tapes, <= 4096 arenas per handle, one launch per step): bit-identical to the reference;
+ *   1 device generator: the same engine (minstd_rand0, integer, bit-exact), the same generate_canonical and the same
+ *     Marsaglia polar method run on the GPU (csrc/gsim_rng.hpp), normals in the reference's order; only log() is
+ *     the device's, so the normals agree with the host's to ~1 ulp and a noisy game matches the reference
+ *     statistically, not bit for bit.  Any batch size, fused launches.
+ * rgs_selftest_rng: the device generator's first n (<= 4096) normals for a seed and the canonical uniforms of its first
+ * n_attempts polar attempts, for comparison with the host's <random>. */
+int rgs_set_noise_mode(rgs_sim *sim, int mode);
+int rgs_selftest_rng(int device_id, long long seed, int n, int n_attempts, double *normals_host, double *canonicals_host,
+                     uint32_t *x_end, int *have);
+
 /* The pooled variants (POOL, APOOL) bind 256 arenas to a workgroup for a launch.  Between fused launches (>= 8 steps,
  * after >= 4 pooled steps of history) the library deals arenas that spent at least 7/8 of those steps in the event pass
  * ("hot": lasting contact) evenly over the workgroups by swapping them against cold arenas; results do not depend on

@@ -484,6 +484,18 @@ void rgso_destroy(void *h) {
 
 int rgso_state_size(void *h) { return 2 + 4 * static_cast<Arena *>(h)->discs; }
 
+// The reference's noise source as the host's <random> produces it (include/GameSim.h:72-73: std::default_random_engine
+// + std::normal_distribution<double>; libstdc++): the first n_normals draws of a generator seeded with `seed`, and the
+// first n_canonicals values of generate_canonical<double, 53> from a second engine with the same seed.  Checker for the
+// HIP stepper's device generator (csrc/gsim_rng.hpp).
+void rgso_rng_streams(long long seed, long long n_normals, double *normals, long long n_canonicals, double *canonicals) {
+  std::default_random_engine e1(static_cast<std::default_random_engine::result_type>(seed));
+  std::normal_distribution<double> d(0.0, 1.0);
+  for (long long i = 0; i < n_normals; ++i) normals[i] = d(e1);
+  std::default_random_engine e2(static_cast<std::default_random_engine::result_type>(seed));
+  for (long long i = 0; i < n_canonicals; ++i) canonicals[i] = std::generate_canonical<double, 53>(e2);
+}
+
 void rgso_reset(void *h, double dt, int winning_score, const double *x0_ball, double noise,
                 int log, const char *logname, int seed, double tau_puck, double tau_player,
                 double player_mass, double puck_mass, double *out_state) {

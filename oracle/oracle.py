@@ -55,6 +55,8 @@ def lib():
                                      C.c_double, C.c_double, _dp, _dp, C.c_longlong, _dp, C.c_int, _dp,
                                      _dp, _llp, C.c_int, C.c_int]
         L.rgso_batch_run.restype = C.c_int
+        L.rgso_rng_streams.argtypes = [C.c_longlong, C.c_longlong, _dp, C.c_longlong, _dp]
+        L.rgso_rng_streams.restype = None
         _lib = L
     return _lib
 
@@ -163,3 +165,10 @@ def batch_run(n_per_team, x0_ball, controls, n_steps, dt=0.05, winning_score=3, 
     if rc != 0:
         raise RuntimeError("rgso_batch_run failed: %d" % rc)
     return dict(state=state, traj=traj, damage=dmg, stats=dict(zip(STAT_NAMES, list(stats))))
+
+
+def rng_streams(seed, n_normals, n_canonicals):
+    """The host's <random> streams for `seed`: (normals, canonical uniforms), as the reference's generator draws them."""
+    normals, canon = np.empty(n_normals), np.empty(n_canonicals)
+    lib().rgso_rng_streams(int(seed), n_normals, _ptr(normals), n_canonicals, _ptr(canon))
+    return normals, canon

@@ -127,6 +127,11 @@ struct StepArgs {
   // tprev[B] = t_ of every arena when the launch began (for the "executed" row of the launch's first step).
   double *rec;
   const double *tprev;
+  // device noise generator (gsim_rng.hpp): per arena the engine state, and the normals generated ahead of use that
+  // the last launch left over ([B][kRngLeft], the first rng_left_n[a] valid)
+  unsigned *rng_x;
+  int *rng_left_n;
+  double *rng_left;
   double *vgrid;                     // two-lane hybrid, n >= 4: velocity rows of the grids (GridView<N, true>)
   int stamps;                        // diagnostic: accumulate s_memtime per phase into stamp_out
   unsigned long long *stamp_out;     // [STAMP_N]
@@ -270,20 +275,23 @@ __device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double
 // RK4_player with the noise term of f_player (cpp:62-88): xdot_v = (u - v)/tau + w_stdev * N(0,1), two
 // draws per f_player call in the order vx, vy, i.e. this axis' draw of stage s is nz[2*s].  The puck
 // passes sigma = 0 (f_puck draws nothing; adding +0.0 changes no value).  IEEE division.
+// DM != 0 (device-generator mode only, where parity is statistical): the division by tau through div_tau<DM>, which
+// equals the IEEE quotient whenever its magnitude window holds (always, outside underflow).
+template <int DM = 0>
 __device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, double tau, double h, double sigma,
-                                                const double *nz) {
+                                                const double *nz, double inv = 0.0) {
   const double half = h / 2.0;
   const double k1p = x.v;
-  const double k1v = (u - coef * x.v) / tau + sigma * nz[0];
+  const double k1v = div_tau<DM>(u - coef * x.v, tau, inv) + sigma * nz[0];
   const double x2v = x.v + k1v * half;
   const double k2p = x2v;
-  const double k2v = (u - coef * x2v) / tau + sigma * nz[2];
+  const double k2v = div_tau<DM>(u - coef * x2v, tau, inv) + sigma * nz[2];
   const double x3v = x.v + k2v * half;
   const double k3p = x3v;
-  const double k3v = (u - coef * x3v) / tau + sigma * nz[4];
+  const double k3v = div_tau<DM>(u - coef * x3v, tau, inv) + sigma * nz[4];
   const double x4v = x.v + k3v * h;
   const double k4p = x4v;
-  const double k4v = (u - coef * x4v) / tau + sigma * nz[6];
+  const double k4v = div_tau<DM>(u - coef * x4v, tau, inv) + sigma * nz[6];
   const double w = h / 6.0;
   Chain r;
   r.p = x.p + (__builtin_fma(k3p, 2.0, __builtin_fma(k2p, 2.0, k1p)) + k4p) * w;

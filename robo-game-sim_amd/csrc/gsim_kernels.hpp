@@ -26,7 +26,7 @@ constexpr int kWavesPerBlock = 4;
 
 // One lane-group per arena; n_steps consecutive steps per launch, state round-trips through
 // the SoA arrays (L2-resident) between steps.
-template <int N, int GW, int FAST, bool NOISE = false>
+template <int N, int GW, int FAST, int NOISE = 0>
 __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_step_wave(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
@@ -44,6 +44,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
       snapshot_state<N>(p, a, k, lg, GW);
     }
   }
+}
+
+// One wavefront per arena with the reference's noise generator ON THE DEVICE (gsim_rng.hpp): n_steps fused steps per
+// launch, any number of arenas; statistical parity with the reference (the exact mode is k_step_wave<.., NOISE = 1> fed
+// with host-drawn tapes).
+template <int N, int FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave_rng(StepArgs p) {
+  extern __shared__ double lds[];
+  using L = WaveLayout<N>;
+  constexpr int WIN = rng_window<N>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long a = (long long)blockIdx.x * kWavesPerBlock + wave;
+  if (a >= p.B) return;
+  double *mine = lds + wave * (L::DOUBLES + WIN);
+  const GridView<N, false> G{mine, nullptr GSIM_GRID_DBG(p)};
+  DevRng rng;
+  rng.buf = mine + L::DOUBLES;
+  rng.cap = WIN;
+  rng.x = p.rng_x[a];
+  rng.have = p.rng_left_n[a];
+  rng.lane_jump = DevRng::lcg_pow_lane(lane);
+  for (int i = lane; i < rng.have; i += 64) rng.buf[i] = p.rng_left[a * kRngLeft + i];
+  wave_sync();
+  for (int k = 0; k < p.n_steps; ++k) {
+    arena_step_group<N, 64, FAST, 2, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lane, 0, 0xFFFFu | (1u << 16), &rng);
+    if (recording(p)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      snapshot_state<N>(p, a, k, lane, 64);
+    }
+  }
+  wave_sync();
+  if (lane == 0) { p.rng_x[a] = rng.x; p.rng_left_n[a] = rng.have < kRngLeft ? rng.have : kRngLeft; }
+  for (int i = lane; i < rng.have && i < kRngLeft; i += 64) p.rng_left[a * kRngLeft + i] = rng.buf[i];
 }
 
 // Hybrid: every lane streams one arena through the step (gsim_lane.hpp); arenas whose overlap
@@ -609,7 +643,8 @@ __global__ void k_reset(double *state, double *tcur, double *damage, const doubl
 }
 
 // What the host needs from one n, resolved at run time through gsim_ops(n).
-enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5 };
+enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5,
+                        LAUNCH_WAVE_RNG = 6 };
 
 struct GsimOps {
   // kind: LaunchKind; mode: DivMode (hybrids) or the wave pass division level 0/1/3 (wave kernels)

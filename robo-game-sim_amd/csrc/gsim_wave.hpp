@@ -21,6 +21,7 @@
 // that are active together; different groups of one wave may diverge freely.
 #pragma once
 #include "gsim_common.hpp"
+#include "gsim_rng.hpp"
 
 namespace gsim {
 
@@ -477,9 +478,13 @@ __device__ __forceinline__ void scan_columns(const StepArgs &p, const GridView<N
 // column (cpp:255-256, 287-288, 294-295 / 309, 331, 338); the puck draws nothing.  `cur` is that
 // cursor; reads past the tape are clamped and reported through consumed[] so the host can redo the
 // step with a longer tape.
-template <int N, int GW, int FAST, bool NOISE = false, bool SPLITV = false, bool COH = false>
+//
+// NOISE: 0 none; 1 host tape as above; 2 the device generator (gsim_rng.hpp, one wavefront per arena): the draws are
+// produced into an LDS window just ahead of their use -- ten grid columns at a time during the fill, one event's worth
+// before each carry-out -- in the same order, and dropped from the window as they are consumed.
+template <int N, int GW, int FAST, int NOISE = 0, bool SPLITV = false, bool COH = false>
 __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict__ ctl, long long a,
-                                 const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask) {
+                                 const GridView<N, SPLITV> G, int lg, int gbase, unsigned discmask, DevRng *rng = nullptr) {
   using L = WaveLayout<N>;
   constexpr int E = L::E, PK = L::PK;
   static_assert(2 * E <= GW, "group too narrow for the (disc, axis) chains");
@@ -488,14 +493,44 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
   if (!(TAS < p.win && TBS < p.win)) return 0u;              // undecided(), cpp:57-60,121
   const double t0 = gld_at<COH>(p.tcur, a, p.n_tcur);
   const double dt = p.dt, dt_col = p.dt_col;
-  const double *tape = NOISE ? p.tape + p.tape_off[a] : nullptr;
-  const int tape_last = NOISE ? p.tape_n[a] - 8 : 0;        // last legal start of an 8-draw record
+  static_assert(NOISE != 2 || (GW == 64 && !SPLITV), "device generator: one wavefront per arena");
+  const double *tape = NOISE == 1 ? p.tape + p.tape_off[a] : (NOISE == 2 ? rng->buf : nullptr);
+  const int tape_last = NOISE == 1 ? p.tape_n[a] - 8 : (NOISE == 2 ? 0x3FFFFFFF : 0);   // last legal start of an 8-draw record
   int cur = 0;                                              // draws consumed so far (group-uniform)
   const bool stamp = GSIM_STAMPS && p.stamps && gbase == 0;               // diagnostic: group 0 times its phases
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
   if (stamp) ts0 = __builtin_amdgcn_s_memtime();
 
   // ---- fill: populateStateGrid, cpp:173-217 ----
+  if (NOISE == 2) {
+    // the same chains, ten columns at a time: all 64 lanes generate the block's 8 * 10 * P draws, the chain lanes use them
+    constexpr int FB = 10;
+    const int e = lg >> 1, ax = lg & 1;
+    const bool chain = lg < 2 * E;
+    Chain x{0.0, 0.0};
+    double u = 0.0, coef = 0.2, tau = p.tau_puck, inv = p.inv_tau_puck;   // cpp:188: puck input is (0, 0)
+    if (chain) {
+      const int row = state_row<N>(e);
+      x.p = gld_at<COH>(p.state, (long long)(row + ax) * B + a, p.n_state);
+      x.v = gld_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state);
+      if (e != PK) { u = ctl[(long long)(2 * e + ax) * B + a]; coef = 1.0; tau = p.tau_player; inv = p.inv_tau_player; }
+      G.ctl(e, ax) = u;
+      G.pos(0, e, ax) = x.p;
+      G.vel(0, e, ax) = x.v;
+    }
+    const double sg = (chain && e != PK) ? p.sigma : 0.0;
+    for (int i0 = 1; i0 <= kGrid; i0 += FB) {
+      rng->ensure(8 * FB * L::P, gbase + lg);
+      if (chain) {
+        for (int i = i0; i < i0 + FB; ++i) {
+          x = rk4_axis_noise<FAST>(x, u, coef, tau, dt_col, sg, tape + 8 * ((i - i0) * L::P + (e != PK ? e : 0)) + ax, inv);
+          G.pos(i, e, ax) = x.p;
+          G.vel(i, e, ax) = x.v;
+        }
+      }
+      rng->consume(8 * FB * L::P, gbase + lg);
+    }
+  } else
   if (lg < 2 * E) {
     const int e = lg >> 1, ax = lg & 1;
     const int row = state_row<N>(e);
@@ -519,7 +554,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
       G.vel(i, e, ax) = x.v;
     }
   }
-  if (NOISE) cur = 8 * kGrid * L::P;
+  if (NOISE == 1) cur = 8 * kGrid * L::P;
   grid_sync<SPLITV>();
   if (stamp) ts1 = __builtin_amdgcn_s_memtime();
 
@@ -680,8 +715,9 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     auto noisy = [&](Chain xx, double hh) {
       const int c0 = cur + 8 * (call * np + slot);
       ++call;
-      return rk4_axis_noise(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax);
+      return rk4_axis_noise<NOISE == 2 ? FAST : 0>(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax, el.inv);
     };
+    if (NOISE == 2) rng->ensure(8 * np * (2 + kGrid - base), gbase + lg);   // this event's draws (cur == 0: the window starts at them)
     if (lg < 4) {
       x.p = G.pos(base - 1, el.d, el.ax);
       x.v = G.vel(base - 1, el.d, el.ax);
@@ -768,6 +804,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     if (NOISE) {                                             // calls per drawing disc: impact, remainder (not after a goal), columns
       const int np_ev = (ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0);
       cur += 8 * np_ev * ((goal ? 1 : 2) + (kGrid - base));
+      if (NOISE == 2) { rng->consume(cur, gbase + lg); cur = 0; }
     }
     for (int chunk = 0;; ++chunk) {
       scan_columns<N, GW, SPLITV>(p, G, ci, cj, lo, hi, t0, dt, dt_col, lg, gbase, done_i, done_j, found_i, found_j, ti, ji,
@@ -809,7 +846,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     gst_at<COH>(p.state, (long long)(row + 2 + ax) * B + a, p.n_state, G.vel(kGrid, e, ax));
   }
   if (lg == 0) {
-    if (NOISE) p.consumed[a] = cur;
+    if (NOISE == 1) p.consumed[a] = cur;
     gst_at<COH>(p.tcur, a, p.n_tcur, t0 + dt);
     if (scored) { gst_at<COH>(p.state, 0 * B + a, p.n_state, TAS); gst_at<COH>(p.state, 1 * B + a, p.n_state, TBS); }
     if (had_events) {

@@ -153,6 +153,25 @@ __global__ void k_deal_match(const int *hot_count, const int *hot_list, const in
   }
 }
 
+// Selftest of the device generator: one wavefront produces the first n normals of the stream seeded with `seed`
+// (n <= window) and, per attempt of the polar loop, the two canonical uniforms it drew.
+__global__ __launch_bounds__(64) void k_selftest_rng(unsigned x0, int n, int n_attempts, double *normals, double *canonicals,
+                                                     unsigned *x_out, int *have_out) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_attempts; i += 64) {               // the uniforms of attempt i, straight from the jump formula
+    const unsigned s = lcg_mulmod(x0, lcg_pow(4u * (unsigned)i));
+    const unsigned d1 = lcg_mulmod(s, kLcgA), d2 = lcg_mulmod(d1, kLcgA), d3 = lcg_mulmod(d2, kLcgA), d4 = lcg_mulmod(d3, kLcgA);
+    canonicals[2 * i] = lcg_canonical(d1, d2);
+    canonicals[2 * i + 1] = lcg_canonical(d3, d4);
+  }
+  DevRng rng;
+  rng.buf = lds; rng.cap = n + kRngSlack; rng.x = x0; rng.have = 0; rng.lane_jump = DevRng::lcg_pow_lane(lane);
+  rng.ensure(n, lane);
+  for (int i = lane; i < n; i += 64) normals[i] = rng.buf[i];
+  if (lane == 0) { *x_out = rng.x; *have_out = rng.have; }
+}
+
 __global__ void k_selftest_divtau(const double *a, long long n, double tau, double inv, double *fast, double *ieee,
                                   double *one) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,6 +236,10 @@ struct rgs_sim {
   int *consumed_dev = nullptr;
   unsigned long long *bak_counters = nullptr;
   size_t tape_cap = 0;             // doubles allocated in tape_dev
+  int noise_mode = 0;              // rgs_set_noise_mode: 0 = exact (host tapes), 1 = device generator (statistical parity)
+  unsigned *rng_x = nullptr;       // device generator: engine state, left-over count and left-over normals per arena
+  int *rng_left_n = nullptr;
+  double *rng_left = nullptr;
   double *vgrid = nullptr;         // split-grid velocity rows (two-lane hybrid, n >= 4)
   size_t vgrid_cap = 0;
   int watch_every = 0;             // pair-watch interval in sub-steps (a divisor of 50); 0 = choose from dt
@@ -594,10 +617,18 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   a.stamps = s->stamps ? 1 : 0;
   a.stamp_out = s->counters + CNT_N;
   a.sigma = 0.0; a.tape = nullptr; a.tape_off = nullptr; a.tape_n = nullptr; a.consumed = nullptr; a.vgrid = nullptr;
+  a.rng_x = nullptr; a.rng_left_n = nullptr; a.rng_left = nullptr;
   a.perm = nullptr; a.heat = nullptr; a.wave_log = s->stamps ? s->wave_log : nullptr;
   a.traj = traj; a.traj_every = traj_every > 0 ? traj_every : 1;
   a.rec = rec; a.tprev = s->tprev;
   if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
+  if (s->sigma != 0.0 && s->noise_mode == 1) {                 // noise from the device generator: fused launch, any batch size
+    a.sigma = s->sigma;
+    a.rng_x = s->rng_x; a.rng_left_n = s->rng_left_n; a.rng_left = s->rng_left;
+    // division by the taus as in the noise-free wave kernel (the reciprocal forms equal '/' inside their magnitude window; this
+    // mode is statistical anyway, rgs_set_fast_division(0) forces IEEE)
+    return launch_kind(s, a, LAUNCH_WAVE_RNG, !use_fast_division(s) ? 0 : (s->one_step_ok ? 3 : 1));
+  }
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
       a.ctl = ctl_dev + (long long)k * stride;
@@ -787,6 +818,7 @@ int rgs_destroy(rgs_sim *s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   dev_free(s, s->state); dev_free(s, s->tcur); dev_free(s, s->tprev);
+  dev_free(s, s->rng_x); dev_free(s, s->rng_left_n); dev_free(s, s->rng_left);
   dev_free(s, s->wave_log); dev_free(s, s->perm); dev_free(s, s->heat); dev_free(s, s->hot_count); dev_free(s, s->hot_list); dev_free(s, s->cold_list); dev_free(s, s->n_swapped);
   dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->tapeoff_dev); dev_free(s, s->tapen_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
   if (s->counters_pin) hipHostFree(s->counters_pin);
@@ -800,9 +832,21 @@ int rgs_destroy(rgs_sim *s) {
 int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_host, int x0_batched, double noise,
               int seed, double tau_puck, double tau_player, double player_mass, double puck_mass) {
   if (!s || !x0_ball_host) return fail(RGS_ERR_ARG, "rgs_reset: null argument");
-  if (noise != 0.0) {
+  if (noise != 0.0 && s->noise_mode == 1) {                    // device generator: engine of arena a seeded with seed + a (cpp:41)
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->rng_x) {
+      HIP_TRY(dev_alloc(s, &s->rng_x, sizeof(unsigned) * s->B, "rng_x"));
+      HIP_TRY(dev_alloc(s, &s->rng_left_n, sizeof(int) * s->B, "rng_left_n"));
+      HIP_TRY(dev_alloc(s, &s->rng_left, sizeof(double) * (size_t)kRngLeft * s->B, "rng_left"));
+    }
+    std::vector<unsigned> x0(s->B);
+    for (long long ar = 0; ar < s->B; ++ar) x0[ar] = lcg_seed((long long)(seed + (int)ar));
+    HIP_TRY(hipMemcpyAsync(s->rng_x, x0.data(), sizeof(unsigned) * s->B, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->rng_left_n, 0, sizeof(int) * s->B, s->stream));   // a re-seeded engine starts a new stream
+    HIP_TRY(hipStreamSynchronize(s->stream));                  // x0 goes out of scope
+  } else if (noise != 0.0) {
     if (s->B > kNoiseMaxArenas)
-      return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 needs host-generated draw tapes and is limited to 4096 arenas per handle");
+      return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 in the exact mode needs host-generated draw tapes and is limited to 4096 arenas per handle (rgs_set_noise_mode(sim, 1) has no limit)");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->bak_state) {
       HIP_TRY(dev_alloc(s, &s->bak_state, sizeof(double) * s->S * s->B, "bak_state"));
@@ -1105,6 +1149,36 @@ int rgs_debug_inject_pool_timeout(rgs_sim *s) {
 int rgs_set_variant(rgs_sim *s, int variant) {
   if (!s || variant < RGS_VARIANT_AUTO || variant > RGS_VARIANT_APOOL) return fail(RGS_ERR_ARG, "rgs_set_variant: bad argument");
   s->variant = variant;
+  return RGS_OK;
+}
+
+int rgs_set_noise_mode(rgs_sim *s, int mode) {
+  if (!s || (mode != 0 && mode != 1)) return fail(RGS_ERR_ARG, "rgs_set_noise_mode: mode must be 0 (exact, host tapes) or 1 (device generator)");
+  s->noise_mode = mode;                                        // takes effect at the next rgs_reset (the engines are seeded there)
+  return RGS_OK;
+}
+
+// The first n normals of the device generator's stream for `seed` (n <= 4096) and the 2 * n_attempts canonical
+// uniforms of its first n_attempts polar attempts; *x_end = engine state after the attempts it evaluated, *have = the
+// normals those produced (>= n).
+int rgs_selftest_rng(int device_id, long long seed, int n, int n_attempts, double *normals_host, double *canonicals_host,
+                     uint32_t *x_end, int *have) {
+  if (!normals_host || !canonicals_host || n < 2 || n > 4096 || n_attempts < 1) return fail(RGS_ERR_ARG, "rgs_selftest_rng: bad argument");
+  HIP_TRY(hipSetDevice(device_id));
+  DeviceScratch scratch;
+  double *nd = nullptr, *cd = nullptr, *misc = nullptr;
+  HIP_TRY(scratch.alloc(&nd, sizeof(double) * n));
+  HIP_TRY(scratch.alloc(&cd, sizeof(double) * 2 * (size_t)n_attempts));
+  HIP_TRY(scratch.alloc(&misc, 16));
+  hipLaunchKernelGGL(k_selftest_rng, dim3(1), dim3(64), sizeof(double) * (n + kRngSlack), 0, lcg_seed(seed), n, n_attempts, nd, cd,
+                     (unsigned *)misc, (int *)misc + 1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(normals_host, nd, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(canonicals_host, cd, sizeof(double) * 2 * (size_t)n_attempts, hipMemcpyDeviceToHost));
+  unsigned two[2];
+  HIP_TRY(hipMemcpy(two, misc, 8, hipMemcpyDeviceToHost));
+  if (x_end) *x_end = two[0];
+  if (have) *have = (int)two[1];
   return RGS_OK;
 }
 

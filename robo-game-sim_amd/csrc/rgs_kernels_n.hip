@@ -56,7 +56,25 @@ hipError_t launch_hybrid2_mode(const StepArgs &args, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int FAST, bool NOISE>
+template <int FAST>
+hipError_t launch_wave_rng(const StepArgs &args, hipStream_t stream) {
+  const long long blocks = (args.B + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t lds = sizeof(double) * (WaveLayout<N>::DOUBLES + rng_window<N>()) * kWavesPerBlock;
+  static std::atomic<unsigned long long> attr_set{0ull};      // > 64 KB of dynamic LDS at the large team sizes: per device, see launch_pool_mode
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (lds > 65536 && (dev >= 64 || !(attr_set.load(std::memory_order_acquire) & bit))) {
+    e = hipFuncSetAttribute((const void *)k_step_wave_rng<N, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (dev < 64) attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((k_step_wave_rng<N, FAST>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, stream, args);
+  return hipGetLastError();
+}
+
+template <int FAST, int NOISE>
 hipError_t launch_wave_level(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + kWavesPerBlock - 1) / kWavesPerBlock;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * kWavesPerBlock;
@@ -67,10 +85,12 @@ hipError_t launch_wave_level(const StepArgs &args, hipStream_t stream) {
 hipError_t step(const StepArgs &args, hipStream_t stream, int kind, int mode) {
   switch (kind) {
     case LAUNCH_WAVE:
-      return mode == 3 ? launch_wave_level<3, false>(args, stream)
-             : mode == 1 ? launch_wave_level<1, false>(args, stream) : launch_wave_level<0, false>(args, stream);
+      return mode == 3 ? launch_wave_level<3, 0>(args, stream)
+             : mode == 1 ? launch_wave_level<1, 0>(args, stream) : launch_wave_level<0, 0>(args, stream);
     case LAUNCH_WAVE_NOISE:
-      return launch_wave_level<0, true>(args, stream);
+      return launch_wave_level<0, 1>(args, stream);
+    case LAUNCH_WAVE_RNG:
+      return mode == 3 ? launch_wave_rng<3>(args, stream) : mode == 1 ? launch_wave_rng<1>(args, stream) : launch_wave_rng<0>(args, stream);
     case LAUNCH_HYBRID:
       return mode == DIV_POW2_ONESTEP ? launch_hybrid_mode<DIV_POW2_ONESTEP>(args, stream)
              : mode == DIV_PLAYER_POW2 ? launch_hybrid_mode<DIV_PLAYER_POW2>(args, stream)

@@ -371,6 +371,12 @@ class BatchedGameSim:
     def set_variant(self, variant):
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
 
+    def set_noise_mode(self, mode):
+        """How noise != 0 is drawn, from the next reset() on: "exact" (default: the reference's <random> on the host,
+        bit-identical, <= 4096 arenas) or "device" (the same generator on the GPU, statistical parity, no limit)."""
+        m = {"exact": 0, "device": 1, 0: 0, 1: 1}[mode]
+        _lib.check(self._L.rgs_set_noise_mode(self._h, m))
+
     def set_rebalance(self, enable):
         """Pooled variants: deal arenas in lasting contact evenly over the workgroups between fused launches (default on)."""
         _lib.check(self._L.rgs_set_rebalance(self._h, int(bool(enable))))

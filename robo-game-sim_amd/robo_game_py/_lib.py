@@ -61,6 +61,8 @@ SIGNATURES = {
     "rgs_debug_wave_log": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int64]),
     "rgs_debug_inject_pool_timeout": (C.c_int, [_vp]),
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
+    "rgs_set_noise_mode": (C.c_int, [_vp, C.c_int]),
+    "rgs_selftest_rng": (C.c_int, [C.c_int, C.c_longlong, C.c_int, C.c_int, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "rgs_set_rebalance": (C.c_int, [_vp, C.c_int]),
     "rgs_get_heat": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "rgs_get_rebalance_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -770,3 +770,58 @@ def test_hot_arenas_are_dealt_evenly_and_results_do_not_change(rgp, oracle, vari
         buf.free()
         sim.close()
     assert np.array_equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 7, 2147483647, 123456789, -5, 4294967297])
+def test_device_noise_generator_reproduces_the_hosts_random(rgp, oracle, seed):
+    """csrc/gsim_rng.hpp against the host's <random> (what the reference draws from): the canonical uniforms of one
+    million engine outputs are bit-equal (integer engine + IEEE arithmetic), the normals -- same polar method, same
+    order, the device's log() -- agree to 2 ulp."""
+    import ctypes as C
+    n, attempts = 4096, 250000                                     # 4 engine outputs per attempt
+    normals, canon = np.empty(n), np.empty(2 * attempts)
+    x_end, have = C.c_uint32(), C.c_int()
+    rgp._lib.check(rgp._lib.lib().rgs_selftest_rng(0, seed, n, attempts, rgp._lib.dptr(normals), rgp._lib.dptr(canon),
+                                                   C.byref(x_end), C.byref(have)))
+    want_n, want_c = oracle.rng_streams(seed, n, 2 * attempts)
+    assert np.array_equal(canon.view(np.uint64), want_c.view(np.uint64))
+    ulp = np.abs(normals.view(np.int64) - want_n.view(np.int64))
+    assert np.sign(normals).tolist() == np.sign(want_n).tolist() and ulp.max() <= 2, ulp.max()
+    assert have.value >= n
+
+
+def test_device_noise_mode_statistics_and_scale(rgp, oracle):
+    """noise > 0 with the device generator (statistical parity): identical arenas that differ only in their seed.
+    (a) Before anything collides the two modes agree to rounding (same uniforms, normals within 2 ulp).  (b) Over 4096
+    noisy games the means and variances of the final state agree with the exact mode's ensemble inside 5-sigma bands.
+    (c) No 4096-arena limit, fused launches; the exact mode still refuses more than 4096."""
+    from robo_game_py import workloads as w
+    n, dt, sigma = 2, 0.05, 0.4
+    B, K = 4096, 30
+    x0 = np.repeat(np.array([[1.0], [0.4], [-1.5], [0.8]]), B, axis=1)
+    _, amp, ph = w.c2_inputs(1, n, seed=3)
+    table = np.repeat(w.circle_controls(amp * 1.5, ph, w.step_times(K, dt)), B, axis=3)
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, noise=sigma, seed_base=100, n_threads=8)
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_noise_mode("device")
+    sim.reset(dt, 1000, x0, sigma, False, "", 100)
+    early = sim.run_table(table[:2], chunk_steps=2)
+    ref2 = oracle.batch_run(n, x0, table[:2], 2, dt=dt, winning_score=1000, noise=sigma, seed_base=100, n_threads=8)
+    assert np.max(np.abs(early - ref2["state"])) < 1e-12                 # (a) two collision-free steps
+    sim.reset(dt, 1000, x0, sigma, False, "", 100)
+    got = sim.run_table(table, chunk_steps=K)                             # one fused launch
+    for r in range(2, got.shape[0]):                                      # (b) every position / velocity row
+        g, o = got[r], ref["state"][r]
+        se = np.sqrt(g.var() / B + o.var() / B)
+        assert abs(g.mean() - o.mean()) <= 5 * se + 1e-12, (r, g.mean(), o.mean(), se)
+        assert abs(g.var() - o.var()) <= 0.2 * max(g.var(), o.var()) + 1e-12, (r, g.var(), o.var())
+    assert got[:, 0].tolist() != got[:, 1].tolist()                       # different seeds, different games
+    sim.close()
+    big = rgp.BatchedGameSim(20000, n)                                    # (c)
+    with pytest.raises(rgp.RgsError):
+        big.reset(dt, 1000, x0[:, :1].repeat(20000, axis=1), sigma, False, "", 5)
+    big.set_noise_mode("device")
+    big.reset(dt, 1000, x0[:, :1].repeat(20000, axis=1), sigma, False, "", 5)
+    st = big.run_table(np.repeat(table[:8, :, :, :1], 20000, axis=3), chunk_steps=8)
+    assert np.isfinite(st).all() and np.unique(st[6]).size > 19000        # A1's x: every arena its own noise (the puck draws none)
+    big.close()
