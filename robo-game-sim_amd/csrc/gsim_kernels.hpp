@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
 // launch, any number of arenas; statistical parity with the reference (the exact mode is k_step_wave<.., NOISE = 1> fed
 // with host-drawn tapes).
 template <int N, int FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_step_wave_rng(StepArgs p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_step_wave_rng(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
   constexpr int WIN = rng_window<N>();

@@ -31,7 +31,7 @@ constexpr unsigned kLcgA = 16807u, kLcgM = 2147483647u;      // minstd_rand0
 constexpr int kRngSlack = 256;                               // room for one iteration's overshoot (<= 128) plus what a step leaves unconsumed
 constexpr int kRngLeft = 256;                                // normals an arena may carry from one launch to the next (global memory)
 template <int N>
-constexpr int rng_window() { return (80 * 2 * N > 8 * 2 * (kGrid + 2) ? 80 * 2 * N : 8 * 2 * (kGrid + 2)) + kRngSlack; }   // doubles of LDS per arena
+constexpr int rng_window() { return 80 * 2 * N + kRngSlack; }   // doubles of LDS per arena: ten columns' draws of all players (an event's blocks need less)
 
 __host__ __device__ constexpr unsigned lcg_mulmod(unsigned x, unsigned c) {     // x * c mod (2^31 - 1); x, c < m
   unsigned long long v = (unsigned long long)x * c;                              // < 2^62

@@ -717,7 +717,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
       ++call;
       return rk4_axis_noise<NOISE == 2 ? FAST : 0>(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax, el.inv);
     };
-    if (NOISE == 2) rng->ensure(8 * np * (2 + kGrid - base), gbase + lg);   // this event's draws (cur == 0: the window starts at them)
+    if (NOISE == 2) rng->ensure(8 * np * 2, gbase + lg);     // the draws of the two RK4 calls around the impact (cur == 0: the window starts at them)
     if (lg < 4) {
       x.p = G.pos(base - 1, el.d, el.ax);
       x.v = G.vel(base - 1, el.d, el.ax);
@@ -792,7 +792,22 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     int ji = -1, ki = -1, jj = -1, kj = -1;
     constexpr int H2 = GW / 2;
     int lo = base, hi = (NOISE || !same_discs) ? kGrid : base;
-    if (NOISE && base < kGrid) {                             // noise: the whole remainder in the reference's call order
+    if (NOISE == 2) {                                        // device generator: ten columns' draws at a time, like the fill
+      rng->consume(8 * np * (goal ? 1 : 2), gbase + lg);     // (after a goal the remainder call did not happen, cpp:324-327)
+      for (int g0 = base + 1; g0 <= kGrid; g0 += 10) {
+        const int g1 = g0 + 9 < kGrid ? g0 + 9 : kGrid;
+        rng->ensure(8 * np * (g1 - g0 + 1), gbase + lg);
+        call = 0;
+        if (lg < 4) {
+          for (int g = g0; g <= g1; ++g) {
+            x = noisy(x, dt_col);                            // cpp:294-295, 338
+            fix_store_column<N, SPLITV>(el, G, x, g, true);
+          }
+        }
+        rng->consume(8 * np * (g1 - g0 + 1), gbase + lg);
+      }
+      grid_sync<SPLITV>();
+    } else if (NOISE && base < kGrid) {                      // host tape: the whole remainder in the reference's call order
       if (lg < 4) {
         for (int g = base + 1; g <= kGrid; ++g) {
           x = noisy(x, dt_col);                              // cpp:294-295, 338
@@ -801,10 +816,9 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
       }
       grid_sync<SPLITV>();
     }
-    if (NOISE) {                                             // calls per drawing disc: impact, remainder (not after a goal), columns
+    if (NOISE == 1) {                                        // calls per drawing disc: impact, remainder (not after a goal), columns
       const int np_ev = (ci != PK ? 1 : 0) + ((is_pair && cj != PK) ? 1 : 0);
       cur += 8 * np_ev * ((goal ? 1 : 2) + (kGrid - base));
-      if (NOISE == 2) { rng->consume(cur, gbase + lg); cur = 0; }
     }
     for (int chunk = 0;; ++chunk) {
       scan_columns<N, GW, SPLITV>(p, G, ci, cj, lo, hi, t0, dt, dt_col, lg, gbase, done_i, done_j, found_i, found_j, ti, ji,
