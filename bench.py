@@ -83,6 +83,10 @@ def parse_args(argv=None):
     ap.add_argument("--jam", action="store_true", help="diagnostic: drive every player towards the arena centre "
                     "(sustained contact, many 49-event steps): the hybrid's worst case")
     ap.add_argument("--calm", action="store_true", help="diagnostic: shrink all motion so no arena ever has an event")
+    ap.add_argument("--arena-offset", type=int, default=0, help="rehearsal / tests: this job's arenas start at this index of the "
+                    "global ensemble (c4: run numbers offset+1 ...), so that one process can re-run exactly another job's rank r shard")
+    ap.add_argument("--ensemble-arenas", type=int, default=0, help="size of the global ensemble the inputs are drawn for "
+                    "(default: arenas x ranks + offset)")
     ap.add_argument("--no-rebalance", action="store_true", help="diagnostic: pooled variants keep every arena on its own workgroup")
     ap.add_argument("--dt", type=float, default=None, help="diagnostic / tools/sweep.py: override the preset's step length")
     args = ap.parse_args(argv)
@@ -212,7 +216,8 @@ def main():
     P = 2 * n
     S = rgp.state_size(n)
     dev = torch.device("cuda", local_rank)
-    lo, hi = rank * B, (rank + 1) * B
+    lo, hi = args.arena_offset + rank * B, args.arena_offset + (rank + 1) * B
+    total_ensemble = args.ensemble_arenas if args.ensemble_arenas > 0 else B * world + args.arena_offset
 
     # ---- inputs, resident in HBM before timing ------------------------------------------
     times = w.step_times(W + K, DT)
@@ -223,7 +228,7 @@ def main():
         x0 = np.repeat(np.array([[-1.0], [0.0], [0.0], [0.0]]), B, axis=1)
         amp, ph = w.mc_inputs(np.arange(lo + 1, hi + 1), n)
     else:
-        x0_all, amp_all, ph_all = w.c2_inputs(B * world, n)      # one global ensemble, sliced per rank
+        x0_all, amp_all, ph_all = w.c2_inputs(total_ensemble, n)   # one global ensemble, sliced per rank
         if args.calm:
             amp_all = amp_all * 0.05
             x0_all = x0_all * np.array([0.2, 0.2, 0.05, 0.05])[:, None]
@@ -415,7 +420,12 @@ def main():
         cores = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
         ref = orc.batch_run(n, x0s, sub, W + K, dt=DT, winning_score=WIN, n_threads=cores)
         delta = float(np.max(np.abs(got - ref["state"])))
+        import hashlib
+        sha = lambda arr: hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
         parity = {"arenas_checked": nc, "steps": W + K, "max_abs_delta_vs_oracle": delta,
+                  "first_rank_states_sha256": sha(got[:, :cs0]), "last_rank_states_sha256": sha(got[:, cs0:]) if cs1 else None,
+                  "global_arena_ids": "%d..%d" % (lo, lo + cs0 - 1) + ("" if world == 1 else " and %d..%d" % (
+                      args.arena_offset + (world - 1) * B, args.arena_offset + (world - 1) * B + cs1 - 1)),
                   "scores_equal": bool(np.array_equal(got[:2], ref["state"][:2])),
                   "bit_identical": bool(np.array_equal(got, ref["state"])),
                   "arena_ids": "0..%d" % (cs0 - 1) + ("" if world == 1 else " (rank 0) and %d..%d (rank %d), read from the "

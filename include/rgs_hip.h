@@ -147,6 +147,9 @@ int rgs_timer_stop(rgs_sim *sim, float *ms_out);
  * RGS_ERR_HIP until the next rgs_reset), [7] 1 if RGS_VARIANT_AUTO currently prefers the wave-per-arena
  * kernel (sustained-contact regime), else 0. */
 int rgs_get_counters(rgs_sim *sim, int64_t *out8);
+/* The same counters, raw: out[0..6] as above, out[7] unused, out[8] = the AUTO flag that rgs_get_counters reports in
+ * [7].  capacity >= 9. */
+int rgs_get_counters_ex(rgs_sim *sim, int64_t *out, int capacity);
 
 /* Diagnostic in-kernel stamps (s_memtime) of the hybrid kernels; only in a library built with
  * `make STAMPS=1` (compiled out otherwise: all zeros), and off until enabled.  enable: bit 0 = stamps on

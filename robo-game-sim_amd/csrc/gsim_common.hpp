@@ -308,13 +308,15 @@ __device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, 
 // writes rows*cols doubles from there), i.e. block k, entry q = damage(row (k+q) % P, column (k+q) / P) -- and a last row
 // "executed": 1.0 if this step advanced the arena's clock (a decided game logs nothing, cpp:121-123), judged against the
 // previous record of the launch (the launch's first step: against StepArgs::tprev).
-__device__ __forceinline__ bool recording(const StepArgs &p) { return p.traj != nullptr || p.rec != nullptr; }
+__device__ __forceinline__ bool recording(const StepArgs &p) { return p.traj != nullptr; }   // (records: REC kernels only, which check p.rec themselves)
 
-template <int N, bool COH = false>
+// REC: only the kernels the host launches for recorded runs carry the record code (k_step_hybrid<.., REC = true>, the
+// noise kernels): inlined into every kernel it cost the pooled 2v2 kernels 100 registers and 5 % (measured).
+template <int N, bool COH = false, bool REC = false>
 __device__ __forceinline__ void snapshot_state(const StepArgs &p, long long a, int k0, int lane, int nl) {
   constexpr int P = 2 * N, S = 2 + 4 * (P + 1), R = 3 + 2 + 2 * P + P * P + 1;
   const long long B = p.B;
-  if (p.rec != nullptr) {
+  if (REC && p.rec != nullptr) {
     double *dst = p.rec + (long long)k0 * R * B;
     for (int r = lane; r < R; r += nl) {
       double v;

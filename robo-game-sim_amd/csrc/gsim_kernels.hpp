@@ -38,10 +38,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
   const GridView<N, false> G{lds + (wave * GPW + grp) * L::DOUBLES, nullptr GSIM_GRID_DBG(p)};
   for (int k = 0; k < p.n_steps; ++k) {
     arena_step_group<N, GW, FAST, NOISE, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lg, lane - lg, 0xFFFFu | (1u << 16));
-    if (recording(p)) {
+    if (recording(p) || (NOISE != 0 && p.rec != nullptr)) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the commit's stores, then the copy's loads
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      snapshot_state<N>(p, a, k, lg, GW);
+      snapshot_state<N, false, NOISE != 0>(p, a, k, lg, GW);
     }
   }
 }
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
   wave_sync();
   for (int k = 0; k < p.n_steps; ++k) {
     arena_step_group<N, 64, FAST, 2, false>(p, p.ctl + (long long)k * p.ctl_stride, a, G, lane, 0, 0xFFFFu | (1u << 16), &rng);
-    if (recording(p)) {
+    if (recording(p) || p.rec != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      snapshot_state<N>(p, a, k, lane, 64);
+      snapshot_state<N, false, true>(p, a, k, lane, 64);
     }
   }
   wave_sync();
@@ -99,7 +99,7 @@ struct HybridGroups {
   static constexpr int GPW = (64 / GW) < FIT ? (64 / GW) : (FIT < 1 ? 1 : FIT);
 };
 
-template <int N, int MODE>
+template <int N, int MODE, bool REC = false>
 __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
   constexpr int FAST = MODE == DIV_IEEE ? 0 : (MODE == DIV_POW2_ONESTEP ? 3 : 1);   // wave pass division
   extern __shared__ double lds[];
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64, GSIM_H1_WAVES) void k_step_hybrid(StepArgs p) {
     }
     __syncthreads();
     if (GSIM_STAMPS && p.stamps) t_wave += __builtin_amdgcn_s_memtime() - t1;
-    if (mine) snapshot_state<N>(p, a, k, 0, 1);
+    if (mine) snapshot_state<N, false, REC>(p, a, k, 0, 1);
   }
   if (GSIM_STAMPS && p.stamps && lane == 0) {
     atomicAdd(&p.stamp_out[STAMP_LANE], t_lane);
@@ -644,7 +644,7 @@ __global__ void k_reset(double *state, double *tcur, double *damage, const doubl
 
 // What the host needs from one n, resolved at run time through gsim_ops(n).
 enum LaunchKind : int { LAUNCH_WAVE = 0, LAUNCH_WAVE_NOISE = 1, LAUNCH_HYBRID = 2, LAUNCH_HYBRID2 = 3, LAUNCH_POOL = 4, LAUNCH_APOOL = 5,
-                        LAUNCH_WAVE_RNG = 6 };
+                        LAUNCH_WAVE_RNG = 6, LAUNCH_HYBRID_REC = 7 };
 
 struct GsimOps {
   // kind: LaunchKind; mode: DivMode (hybrids) or the wave pass division level 0/1/3 (wave kernels)

@@ -713,6 +713,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
                        scales_exactly(s->dt_col, 1.0 / s->tau_player) && scales_exactly(s->dt_col / 6.0, 1.0 / s->tau_player);
   const int div_mode = !fast ? DIV_IEEE
                        : (fold_ok ? (s->one_step_ok ? DIV_POW2_ONESTEP : DIV_PLAYER_POW2) : DIV_MARKSTEIN);
+  if (rec != nullptr)                                          // log records: the one-lane hybrid instantiated with the record code
+    return launch_kind(s, a, LAUNCH_HYBRID_REC, div_mode);     // (any variant gives the same values; the others do not carry that code)
   if (variant == RGS_VARIANT_HYBRID2) {
     const size_t need = gsim_ops(s->n)->vgrid_doubles(s->B);   // velocity rows of every block's grids
     if (need > s->vgrid_cap) {
@@ -1075,6 +1077,20 @@ int rgs_get_counters(rgs_sim *s, int64_t *out8) {
   s->pooled_in_flight = false;
   if (out8[6] != 0) s->poisoned = true;
   out8[7] = s->auto_wave ? 1 : 0;
+  if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
+  return RGS_OK;
+}
+
+// The 8 device counters as they are (out[7] is not used), then out[8] = AUTO's current preference for the wave-per-arena
+// kernel.  capacity >= 9.
+int rgs_get_counters_ex(rgs_sim *s, int64_t *out, int capacity) {
+  if (!s || !out || capacity < 9) return fail(RGS_ERR_ARG, "rgs_get_counters_ex: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(out, s->counters, sizeof(unsigned long long) * CNT_N, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->pooled_in_flight = false;
+  if (out[CNT_POOL_TIMEOUT] != 0) s->poisoned = true;
+  out[8] = s->auto_wave ? 1 : 0;
   if (s->poisoned) return fail(RGS_ERR_HIP, kPoolTimeoutText);
   return RGS_OK;
 }

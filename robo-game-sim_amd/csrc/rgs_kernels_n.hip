@@ -16,11 +16,11 @@ namespace {
 
 constexpr int N = GSIM_N;
 
-template <int MODE>
+template <int MODE, bool REC = false>
 hipError_t launch_hybrid_mode(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + 63) / 64;
   const size_t lds = sizeof(double) * WaveLayout<N>::DOUBLES * HybridGroups<N>::GPW;
-  hipLaunchKernelGGL((k_step_hybrid<N, MODE>), dim3((unsigned)blocks), dim3(64), lds, stream, args);
+  hipLaunchKernelGGL((k_step_hybrid<N, MODE, REC>), dim3((unsigned)blocks), dim3(64), lds, stream, args);
   return hipGetLastError();
 }
 
@@ -96,6 +96,11 @@ hipError_t step(const StepArgs &args, hipStream_t stream, int kind, int mode) {
              : mode == DIV_PLAYER_POW2 ? launch_hybrid_mode<DIV_PLAYER_POW2>(args, stream)
              : mode == DIV_MARKSTEIN ? launch_hybrid_mode<DIV_MARKSTEIN>(args, stream)
                                      : launch_hybrid_mode<DIV_IEEE>(args, stream);
+    case LAUNCH_HYBRID_REC:
+      return mode == DIV_POW2_ONESTEP ? launch_hybrid_mode<DIV_POW2_ONESTEP, true>(args, stream)
+             : mode == DIV_PLAYER_POW2 ? launch_hybrid_mode<DIV_PLAYER_POW2, true>(args, stream)
+             : mode == DIV_MARKSTEIN ? launch_hybrid_mode<DIV_MARKSTEIN, true>(args, stream)
+                                     : launch_hybrid_mode<DIV_IEEE, true>(args, stream);
     case LAUNCH_POOL:
       return mode == DIV_POW2_ONESTEP ? launch_pool_mode<DIV_POW2_ONESTEP, false>(args, stream)
              : mode == DIV_PLAYER_POW2 ? launch_pool_mode<DIV_PLAYER_POW2, false>(args, stream)

@@ -341,11 +341,15 @@ class BatchedGameSim:
             _lib.check(self._L.rgs_set_damage(self._h, _lib.dptr(d)))
 
     def counters(self):
-        out = (C.c_int64 * 8)()
-        _lib.check(self._L.rgs_get_counters(self._h, out))
+        out = (C.c_int64 * 9)()
+        if hasattr(self._L, "rgs_get_counters_ex"):
+            _lib.check(self._L.rgs_get_counters_ex(self._h, out, 9))
+        else:                                                  # an older A/B build (RGS_LIB_SUFFIX)
+            _lib.check(self._L.rgs_get_counters(self._h, out))
+            out[8], out[7] = out[7], 0
         names = ["resolved", "cap_hits", "base_overflow", "skipped_after_goal", "event_steps", "flagged"]
         d = dict(zip(names, list(out)[:6]))
-        d["auto_prefers_wave"] = int(out[7])
+        d["auto_prefers_wave"] = int(out[8])
         return d
 
     def stamps(self, enable=True, clear=False):

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rgs_timer_start": (C.c_int, [_vp]),
     "rgs_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "rgs_get_counters": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rgs_get_counters_ex": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int]),
     "rgs_get_stamps": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "rgs_debug_check_guards": (C.c_int, [_vp]),
     "rgs_debug_wave_log": (C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int64]),
@@ -125,6 +126,8 @@ def lib():
                 "there is no CPU fallback." % (LIB_PATH, CSRC))
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("RGS_LIB_SUFFIX") and not hasattr(L, name):
+                continue                   # an older A/B build (tools/ab_libs.sh) may lack the newest entry points
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args

@@ -113,3 +113,22 @@ def test_bench_starts_its_own_ranks_and_checks_both_shards():
     p = d["parity"]
     assert p["bit_identical"] and p["arenas_checked"] == 1024 and "8192..8703" in p["arena_ids"]
     assert d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("config,extra", [("c4", []), ("c5", ["--steps", "60", "--no-streamed"])])
+def test_sharded_configs_rank1_equals_a_single_process_run_of_its_arenas(config, extra):
+    """The configs BASELINE shards over GPUs (C4: Monte-Carlo runs with per-run seeds lo+1..hi, py/MonteCarlo.py:23-45; C5:
+    4v4 ensemble), two ranks on this box's one GPU (gloo): what rank 1 computed for its first 1024 arenas -- read from the
+    all-gathered ensemble on rank 0, scores and with them undecided() included -- must be exactly what ONE process computes
+    for the same global arenas (runs 4097.. resp. arenas 4096..), and both must equal the oracle."""
+    two = _bench("--config", config, "--gpus", "2", "--backend", "gloo", "--force-device", "0", "--arenas", "4096",
+                 "--cpu-sample-arenas", "2048", "--cpu-seconds", "0.5", *extra)
+    assert two["n_gpus"] == 2 and two["collective"]["ranks"] == 2
+    p2 = two["parity"]
+    assert p2["bit_identical"] and p2["scores_equal"] and p2["arenas_checked"] == 2048 and "4096..5119" in p2["global_arena_ids"]
+    one = _bench("--config", config, "--gpus", "1", "--arenas", "4096", "--arena-offset", "4096", "--ensemble-arenas", "8192",
+                 "--cpu-sample-arenas", "1024", "--cpu-seconds", "0.5", *extra)
+    p1 = one["parity"]
+    assert p1["bit_identical"] and p1["arenas_checked"] == 1024 and p1["global_arena_ids"] == "4096..5119"
+    assert p1["first_rank_states_sha256"] == p2["last_rank_states_sha256"]
+    assert p1["first_rank_states_sha256"] != p2["first_rank_states_sha256"]          # different runs, different games

@@ -825,3 +825,31 @@ def test_device_noise_mode_statistics_and_scale(rgp, oracle):
     st = big.run_table(np.repeat(table[:8, :, :, :1], 20000, axis=3), chunk_steps=8)
     assert np.isfinite(st).all() and np.unique(st[6]).size > 19000        # A1's x: every arena its own noise (the puck draws none)
     big.close()
+
+
+@pytest.mark.parametrize("n", [4, 6, 7])
+def test_pile_ups_in_the_split_grid(rgp, oracle, n):
+    """Two-lane hybrid with the split grid (4v4, 6v6, 7v7), everybody pulled to the centre: multi-disc pile-ups, where a
+    re-integrated disc keeps meeting discs the lane pass had not flagged (their velocity rows are read from the global
+    scratch).  State, damage and event counts as the oracle's."""
+    from robo_game_py import workloads as w
+    B, K, dt = 192, 90, 0.05
+    x0, amp, ph = w.c2_inputs(B, n, seed=300 + n)
+    x0 = x0 * np.array([0.3, 0.3, 0.5, 0.5])[:, None]
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_variant(3)
+    st0 = sim.reset(dt, 1000, x0)
+    P = 2 * n
+    table = np.empty((K, P, 2, B))
+    for e in range(P):                                             # constant pull towards the centre, strength from amp
+        d = -st0[6 + 4 * e:8 + 4 * e]
+        d = d / np.maximum(np.sqrt((d * d).sum(0)), 1e-9)
+        table[:, e] = (amp[e] * 1.5 * d)[None]
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=1000, n_threads=8, want_damage=True)
+    got = sim.run_table(table, chunk_steps=K)
+    c = sim.counters()
+    assert_same(got, ref["state"], "split grid n=%d" % n)
+    assert_same(sim.damage().reshape(P * P, B), ref["damage"], "damage")
+    assert c["resolved"] == ref["stats"]["resolved"] and c["cap_hits"] == ref["stats"]["cap_hits"]
+    assert ref["stats"]["resolved"] > 20 * B
+    sim.close()
