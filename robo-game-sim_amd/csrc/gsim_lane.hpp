@@ -354,9 +354,11 @@ __device__ __forceinline__ bool lane_step(const StepArgs &p, const double *__res
 //
 // The chains of the two axes never interact inside an event-free step; only the overlap watch
 // needs both (dx^2 + dy^2), which one DPP quad exchange per pair provides.  Same arithmetic per
-// chain as lane_step, so the same bits.  What it buys: half the registers per lane and twice the
-// waves (65 536 arenas = 2048 waves = two per SIMD), so while one wave sits in its latency-bound
-// wave pass the SIMD's other wave keeps the FP64 pipe busy.
+// chain as lane_step, so the same bits.  What it buys: half the chains per lane, which is what lets the
+// large teams fit at all (7v7: 15 chains per lane instead of 30) and, with the split grid, two arenas' wave
+// passes side by side per wavefront.  It does NOT buy a second wavefront per SIMD: k_step_hybrid2 needs 274
+// (2v2) to 256 + 242 (7v7) registers, one wavefront per SIMD like every other stepping kernel (65 536 arenas =
+// 2048 wavefronts run as two successive waves over the chip's 1024 SIMDs).
 __device__ __forceinline__ unsigned quad_xor1_u32(unsigned x) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);
 }
