@@ -34,7 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "robo-game-sim_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes/2 (fp64 half rate) x 2 flop x 2.4 GHz
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc.json")
 
 # config -> (n per team, arenas per GPU, dt, winning score, default timed steps, default warm-up steps)
 PRESETS = {"c2": (2, 65536, 0.01, 1000000, 1000, 10), "c3": (7, 65536, 0.01, 1000000, 1000, 10),

@@ -46,6 +46,9 @@
 #ifndef GSIM_H2_SPLIT_4
 #define GSIM_H2_SPLIT_4 1          // the same at 4v4
 #endif
+#ifndef GSIM_TAIL_ANCHOR_FROM
+#define GSIM_TAIL_ANCHOR_FROM 1    // team size from which arena_step_group ends with a real vector instruction (see there)
+#endif
 #ifndef GSIM_H2_SPLIT_5
 #define GSIM_H2_SPLIT_5 0          // diagnostic: the split grid at 5v5 too (the instantiation that once gave wrong results)
 #endif

@@ -885,7 +885,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
   // merges the EXEC restores of the nested tail regions (lane 0's stores, the aggregated atomics' single lane) into the
   // caller's join and then rematerialises loop-carried constants in the block in between, i.e. under the innermost,
   // single-lane EXEC (tools/isa_lint.py caught k_step_hybrid2<5,3> doing exactly that).
-  asm volatile("v_nop");
+  if constexpr (N >= GSIM_TAIL_ANCHOR_FROM) asm volatile("v_nop");
   return (had_events ? 1u : 0u) | (saw_predicate ? 2u : 0u);
 }
 

@@ -3,7 +3,7 @@
 # Pass 1: kernel trace + stats (per-kernel durations).  Passes 2-4: PMC counters, each in its own run with
 # --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md "rocprofv3 PMC slots").
 # The program itself follows `--` (no env/bash hop).  Output: gpurun_out/prof/<tag>/, summarised by
-# tools/prof_summarize.py into the entry bench.py looks up in profiles/r02/pmc.json.
+# tools/prof_summarize.py into the entry bench.py looks up in profiles/r03/pmc.json.
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 
 Picks the TIMED launch of the stepping kernel (the last k_step_* dispatch: bench.py fuses all timed steps into
 one launch and profiling runs skip the host-streamed leg) and records its duration and counters, keyed the way
-bench.py looks profiles up (profiles/r02/pmc.json): "<config>:n<n>:B<arenas>:K<steps>:W<warmup>:L<launches>:v<variant>".
+bench.py looks profiles up (profiles/r03/pmc.json): "<config>:n<n>:B<arenas>:K<steps>:W<warmup>:L<launches>:v<variant>".
 """
 import csv
 import glob

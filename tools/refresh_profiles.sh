@@ -1,6 +1,6 @@
 # Round-end evidence on the GPU box (after tools/gate.sh): rocprofv3 passes of every bench shape (tools/prof.sh) and the
 # whole-ensemble parity runs.  Outputs: gpurun_out/prof/<tag>/ and gpurun_out/whole/; tools/pmc_merge.py then
-# installs the summaries into profiles/r02/.
+# installs the summaries into profiles/r03/.
 set -e
 cd $GRAFT_REPO_ROOT
 bash tools/prof.sh c2_default --config c2 > /dev/null
