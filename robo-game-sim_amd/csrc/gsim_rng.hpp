@@ -45,6 +45,7 @@ __host__ __device__ constexpr unsigned lcg_pow(unsigned e) {                    
   return r;
 }
 __host__ __device__ inline unsigned lcg_pow_rt(unsigned e) { return lcg_pow(e); }   // the same at run time
+
 __host__ __device__ inline unsigned lcg_seed(long long s) {                      // linear_congruential_engine::seed, random.tcc:118-127
   const unsigned long long u = (unsigned long long)s;                            // result_type is 64-bit unsigned on this ABI
   const unsigned x = (unsigned)(u % kLcgM);
@@ -57,7 +58,10 @@ __device__ __forceinline__ double lcg_canonical(unsigned d1, unsigned d2) {
   const double tmp = 4611686009837453316.0;                                      // fl(r * r): the literal rounds to the same double
   double sum = (double)(d1 - 1u);
   sum = sum + (double)(d2 - 1u) * r;
-  double ret = div_ieee(sum, tmp);
+  // sum / tmp, correctly rounded: reciprocal + two Markstein corrections (div_tau<1>, gsim_common.hpp; exact for any
+  // divisor whose significand does not end in a run of ones and a dividend that is 0 or in [1, 2^63) -- both hold
+  // here), 5 full-rate instructions instead of the IEEE sequence's 11; the bit-equality test of the uniforms covers it
+  double ret = div_tau<1>(sum, tmp, 1.0 / tmp);
   if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;                                    // nextafter(1, 0)
   return ret;
 }
