@@ -46,6 +46,9 @@
 #ifndef GSIM_H2_SPLIT_4
 #define GSIM_H2_SPLIT_4 1          // the same at 4v4
 #endif
+#ifndef GSIM_SCAN_KNOWN
+#define GSIM_SCAN_KNOWN 1          // wave pass, n <= 3: first-scan candidates reuse the predicate pass' distance tests and a pair's time from the partner's side
+#endif
 #ifndef GSIM_TAIL_ANCHOR_FROM
 #define GSIM_TAIL_ANCHOR_FROM 1    // team size from which arena_step_group ends with a real vector instruction (see there)
 #endif

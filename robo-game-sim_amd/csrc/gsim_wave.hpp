@@ -159,18 +159,32 @@ __device__ __forceinline__ double disc_radius(int e) { return e == 2 * N ? kRPuc
 // overlap predicates of the column (4 wall zones, E-1 distances) are evaluated first in straight-line
 // code over one batch of LDS loads; only a column with a predicate set -- rare outside sustained
 // contact -- goes on to the back-tracking arithmetic.
-template <int N, bool SPLITV>
+// A pair's back-tracked time (cpp:482-494) is the same from either side (all differences change sign together, every product
+// is unchanged), so in the first scans, where both discs of a near pair are evaluated at the same column, the second
+// one takes it from here.
+struct PairMemo {
+  int a, b;                  // the pair last evaluated by this lane at the current column: disc a scanned, partner b
+  bool valid;                // it had a candidate (dv.dp < 0 and d >= 0) ...
+  double tc;                 // ... at this time
+};
+
+// KNOWN: the caller has the overlap predicates of this column already (column_flags): `near` = the discs within reach of
+// `id`; the distance tests are not repeated, and `memo` carries the last pair's result over to the partner's turn.
+template <int N, bool SPLITV, bool KNOWN = false>
 __device__ __forceinline__ void column_candidate(const StepArgs &p, const GridView<N, SPLITV> &G, int g, int id, double t0,
-                                                 double dt_col, double &best_t, int &best_j, int &best_kind) {
+                                                 double dt_col, double &best_t, int &best_j, int &best_kind,
+                                                 unsigned known_near = 0u, PairMemo *memo = nullptr) {
   constexpr int E = 2 * N + 1, PK = 2 * N;
   const double rad = id == PK ? kRPuck : kRPlayer;
   const double kpx = G.pos(g, id, 0), kpy = G.pos(g, id, 1);
-  unsigned near = 0u;
+  unsigned near = known_near;
+  if (!KNOWN) {
 #pragma unroll
-  for (int o = 0; o < E; ++o) {                              // cpp:466-471, every other disc
-    const double ddx = kpx - G.pos(g, o, 0), ddy = kpy - G.pos(g, o, 1);
-    const double le = (o == PK || id == PK) ? p.le_pk : p.le_pp;
-    near |= (ddx * ddx + ddy * ddy <= le) ? (1u << o) : 0u;
+    for (int o = 0; o < E; ++o) {                            // cpp:466-471, every other disc
+      const double ddx = kpx - G.pos(g, o, 0), ddy = kpy - G.pos(g, o, 1);
+      const double le = (o == PK || id == PK) ? p.le_pk : p.le_pp;
+      near |= (ddx * ddx + ddy * ddy <= le) ? (1u << o) : 0u;
+    }
   }
   near &= ~(1u << id);
   const bool up = kpy + rad >= kY / 2.0, down = kpy - rad <= -kY / 2.0;      // cpp:374, 397
@@ -202,16 +216,25 @@ __device__ __forceinline__ void column_candidate(const StepArgs &p, const GridVi
   while (near != 0u) {                                       // cpp:482-497, ascending o = entity order
     const int o = __builtin_ctz(near);
     near &= near - 1u;
-    const double sigma = rad + (o == PK ? kRPuck : kRPlayer);
-    const double dpx = G.pos(gm, o, 0) - mpx, dpy = G.pos(gm, o, 1) - mpy;       // cpp:484
-    const double dvx = G.vel(gm, o, 0) - mvx, dvy = G.vel(gm, o, 1) - mvy;       // cpp:485
-    const double dpdv = dpx * dvx + dpy * dvy;
-    const double dvdv = dvx * dvx + dvy * dvy;
-    const double dpdp = dpx * dpx + dpy * dpy;
-    const double d = dpdv * dpdv - dvdv * (dpdp - sigma * sigma);                // cpp:487
-    const double dvdp = dvx * dpx + dvy * dpy;
-    if ((dvdp < 0) & (d >= 0)) {                             // discs in resting contact fail this at every column
-      const double tc = t_m + max0(div_ieee(-(dvdp + sqrt_ieee(d)), dvdv));      // cpp:490
+    bool have = false;
+    double tc = 0.0;
+    if (KNOWN && memo->a == o && memo->b == id) {            // evaluated from the partner's side a moment ago: same value
+      have = memo->valid;
+      tc = memo->tc;
+    } else {
+      const double sigma = rad + (o == PK ? kRPuck : kRPlayer);
+      const double dpx = G.pos(gm, o, 0) - mpx, dpy = G.pos(gm, o, 1) - mpy;     // cpp:484
+      const double dvx = G.vel(gm, o, 0) - mvx, dvy = G.vel(gm, o, 1) - mvy;     // cpp:485
+      const double dpdv = dpx * dvx + dpy * dvy;
+      const double dvdv = dvx * dvx + dvy * dvy;
+      const double dpdp = dpx * dpx + dpy * dpy;
+      const double d = dpdv * dpdv - dvdv * (dpdp - sigma * sigma);              // cpp:487
+      const double dvdp = dvx * dpx + dvy * dpy;
+      have = (dvdp < 0) & (d >= 0);                          // discs in resting contact fail this at every column
+      if (have) tc = t_m + max0(div_ieee(-(dvdp + sqrt_ieee(d)), dvdv));         // cpp:490
+      if (KNOWN) { memo->a = id; memo->b = o; memo->valid = have; memo->tc = tc; }
+    }
+    if (have) {
       const bool ok = tc < best_t;
       best_t = ok ? tc : best_t;
       best_j = ok ? o : best_j;
@@ -225,8 +248,10 @@ __device__ __forceinline__ void column_candidate(const StepArgs &p, const GridVi
 // the (disc, column) pairs for which column_candidate can produce anything.  `consider`: discs that
 // can have a flag at all (the lane pass' conservative watch; all ones when unknown) -- a pair can only
 // overlap if the watch fired for both of its discs.
+// near_of (small teams, may be null): per disc, the discs within reach at this column -- what column_candidate<KNOWN> takes.
 template <int N, bool SPLITV>
-__device__ __forceinline__ unsigned column_flags(const StepArgs &p, const GridView<N, SPLITV> &G, int g, unsigned consider) {
+__device__ __forceinline__ unsigned column_flags(const StepArgs &p, const GridView<N, SPLITV> &G, int g, unsigned consider,
+                                                 unsigned *near_of = nullptr) {
   constexpr int E = 2 * N + 1, PK = 2 * N;
   unsigned fl = 0u;
   if constexpr (N <= 4) {                                    // small teams: straight-line code over one batch of LDS loads
@@ -241,7 +266,9 @@ __device__ __forceinline__ unsigned column_flags(const StepArgs &p, const GridVi
       for (int o = e + 1; o < E; ++o) {
         const double ddx = px - G.pos(g, o, 0), ddy = py - G.pos(g, o, 1);
         const double le = (e == PK || o == PK) ? p.le_pk : p.le_pp;
-        fl |= (ddx * ddx + ddy * ddy <= le) ? ((1u << e) | (1u << o)) : 0u;
+        const bool nr = ddx * ddx + ddy * ddy <= le;
+        fl |= nr ? ((1u << e) | (1u << o)) : 0u;
+        if (near_of != nullptr) { near_of[e] |= nr ? (1u << o) : 0u; near_of[o] |= nr ? (1u << e) : 0u; }
       }
     }
   } else {                                                   // large teams (up to 105 pairs): loops over the flagged discs only,
@@ -580,7 +607,14 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     unsigned open = consider;                                // discs still looking for their first event
     for (int g0 = scan_from; g0 <= kGrid && open != 0u; g0 += GW) {
       const int g = g0 + lg;
-      const unsigned fl = g <= kGrid ? (column_flags<N, SPLITV>(p, G, g, consider) & open) : 0u;
+      constexpr bool KN = GSIM_SCAN_KNOWN && N <= 3;       // the candidates reuse this pass' distance tests and each pair's time
+      unsigned near_of[KN ? E : 1];
+      if (KN) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) near_of[e] = 0u;
+      }
+      PairMemo memo{-1, -1, false, 0.0};
+      const unsigned fl = g <= kGrid ? (column_flags<N, SPLITV>(p, G, g, consider, KN ? near_of : nullptr) & open) : 0u;
       if (group_ballot<GW>(fl != 0u, gbase) == 0ull) continue;
       saw_predicate = true;
       unsigned todo = 0u;                                    // union of the lanes' flags (group-uniform)
@@ -593,7 +627,14 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
         double bt = 1.0e9;
         int bj = -1, bk = -1;
         if ((fl >> id) & 1u) {
-          column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, bt, bj, bk);
+          if constexpr (KN) {
+            unsigned nr = 0u;
+#pragma unroll
+            for (int e = 0; e < E; ++e) nr = (e == id) ? near_of[e] : nr;
+            column_candidate<N, SPLITV, true>(p, G, g, id, t0, dt_col, bt, bj, bk, nr, &memo);
+          } else {
+            column_candidate<N, SPLITV>(p, G, g, id, t0, dt_col, bt, bj, bk);
+          }
           hit = (bt - t0 < dt);                              // cpp:501
         }
         const unsigned long long m = group_ballot<GW>(hit, gbase);
