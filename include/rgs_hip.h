@@ -98,6 +98,21 @@ int rgs_record_size(int n_per_team);
 int rgs_step_device_record(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps,
                            double *rec_dev);
 
+/* The reference's log FILES written by the library: replaces Logger::open / log / logVectors
+ * (include/utils.h:55-75) as driven by GameSim::reset (src/GameSim.cpp:48-53) and GameSim::run (:160-170), for many
+ * arenas of a batch at once.
+ *   rgs_log_open         creates / truncates paths[q] (as std::ofstream::open does) for arena arena_ids[q], q < n_files;
+ *                        a log that is still open is closed first;
+ *   rgs_step_device_log  steps like rgs_step_device_record (one fused launch) and appends to each open file the
+ *                        records of the steps its arena executed: R - 1 = 29 (2v2) native-endian doubles per step,
+ *                        nothing for a decided game (cpp:121-123) -- byte for byte what the reference writes; the
+ *                        per-file gather runs on the device, the writes on up to 16 host threads; returns when the
+ *                        data is with the operating system;
+ *   rgs_log_close        closes the files (also done by rgs_destroy). */
+int rgs_log_open(rgs_sim *sim, int n_files, const int *arena_ids, const char *const *paths);
+int rgs_step_device_log(rgs_sim *sim, const double *controls_dev, int64_t step_stride, int n_steps);
+int rgs_log_close(rgs_sim *sim);
+
 int rgs_sync(rgs_sim *sim);
 
 /* The value GameSim::run / reset return (state_.vector(), src/GameSim.cpp:54,123), for all arenas. */

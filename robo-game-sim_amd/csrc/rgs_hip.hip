@@ -8,9 +8,14 @@
 #include <cstdlib>
 #include <random>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <cerrno>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "../../include/rgs_hip.h"
 #include "gsim_kernels.hpp"
@@ -153,6 +158,22 @@ __global__ void k_deal_match(const int *hot_count, const int *hot_list, const in
   }
 }
 
+// Log writer, device half: rec (K, R, B) -- the record of every step for every arena, row R-1 = 1.0 where the step executed --
+// to runs (n_files, K, R-1): arena ids[q]'s executed records one after another (a decided game logs nothing, cpp:121-123, so
+// the executed steps are a prefix of the chunk), and count[q] = how many.  Thread <-> (file, step): consecutive threads
+// read consecutive arenas.
+__global__ void k_gather_runs(const double *rec, long long B, int R, int K, int n_files, const int *ids, double *runs, int *count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n_files * K) return;
+  const int q = (int)(i % n_files), k = (int)(i / n_files);
+  const long long a = ids[q];
+  const double *src = rec + (long long)k * R * B + a;
+  if (src[(long long)(R - 1) * B] == 0.0) return;
+  atomicAdd(&count[q], 1);
+  double *dst = runs + ((long long)q * K + k) * (R - 1);
+  for (int r = 0; r < R - 1; ++r) dst[r] = src[(long long)r * B];
+}
+
 // Selftest of the device generator: one wavefront produces the first n normals of the stream seeded with `seed`
 // (n <= window) and, per attempt of the polar loop, the two canonical uniforms it drew.
 __global__ __launch_bounds__(64) void k_selftest_rng(unsigned x0, int n, int n_attempts, double *normals, double *canonicals,
@@ -236,6 +257,14 @@ struct rgs_sim {
   int *consumed_dev = nullptr;
   unsigned long long *bak_counters = nullptr;
   size_t tape_cap = 0;             // doubles allocated in tape_dev
+  // native log writer (rgs_log_open / rgs_step_device_log / rgs_log_close)
+  std::vector<int> log_fds;
+  int *log_ids = nullptr, *log_count = nullptr;      // device: arena of file q, executed records of file q in the last chunk
+  double *log_rec = nullptr, *log_runs = nullptr;    // device: (cap, R, B) records of a chunk; (n_files, cap, R-1) per-file runs
+  double *log_runs_host = nullptr;                   // pinned mirror of log_runs (lent by the process-wide staging buffer when free)
+  bool log_runs_borrowed = false;
+  int *log_count_host = nullptr;
+  int log_cap = 0;                                   // steps the chunk buffers hold
   int noise_mode = 0;              // rgs_set_noise_mode: 0 = exact (host tapes), 1 = device generator (statistical parity)
   unsigned *rng_x = nullptr;       // device generator: engine state, left-over count and left-over normals per arena
   int *rng_left_n = nullptr;
@@ -823,6 +852,7 @@ int rgs_destroy(rgs_sim *s) {
   dev_free(s, s->rng_x); dev_free(s, s->rng_left_n); dev_free(s, s->rng_left);
   dev_free(s, s->wave_log); dev_free(s, s->perm); dev_free(s, s->heat); dev_free(s, s->hot_count); dev_free(s, s->hot_list); dev_free(s, s->cold_list); dev_free(s, s->n_swapped);
   dev_free(s, s->vgrid); dev_free(s, s->tape_dev); dev_free(s, s->bak_state); dev_free(s, s->bak_tcur); dev_free(s, s->bak_damage); dev_free(s, s->consumed_dev); dev_free(s, s->tapeoff_dev); dev_free(s, s->tapen_dev); dev_free(s, s->bak_counters); dev_free(s, s->damage); dev_free(s, s->ctl); dev_free(s, s->counters); dev_free(s, s->flags);
+  (void)rgs_log_close(s);
   if (s->counters_pin) hipHostFree(s->counters_pin);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -914,6 +944,143 @@ int rgs_step_device_record(rgs_sim *s, const double *controls_dev, int64_t step_
   // gsim_common.hpp).  tprev = the clocks before the launch, for the "executed" row of its first step.
   HIP_TRY(hipMemcpyAsync(s->tprev, s->tcur, sizeof(double) * s->B, hipMemcpyDeviceToDevice, s->stream));
   return launch_steps(s, controls_dev, step_stride, n_steps, nullptr, 0, rec_dev);
+}
+
+// ---- native log writer: the reference's Logger (include/utils.h:55-75) opened by GameSim::reset (cpp:48-53)
+// and fed by every executed step (cpp:160-170), for many arenas at once ----
+namespace {
+// Page-locking the staging buffer of the log writer costs more than a whole logged chunk (tens of MB: ~10 ms to pin, ~5 ms to
+// release), and Monte-Carlo drivers create one handle per ensemble: ONE staging buffer per device is kept for the life of the
+// process and lent to the handle that asks first; a second concurrent logger gets a private one.
+struct PinnedLoan { double *ptr = nullptr; size_t bytes = 0; bool lent = false; };
+std::mutex g_pin_mutex;
+PinnedLoan g_pin[64];
+
+hipError_t pinned_borrow(int device, size_t bytes, double **out, bool *borrowed) {
+  *borrowed = false;
+  if (device >= 0 && device < 64) {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    PinnedLoan &L = g_pin[device];
+    if (!L.lent) {
+      if (L.bytes < bytes) {
+        if (L.ptr) (void)hipHostFree(L.ptr);
+        L.ptr = nullptr; L.bytes = 0;
+        hipError_t e = hipHostMalloc((void **)&L.ptr, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        L.bytes = bytes;
+      }
+      L.lent = true; *out = L.ptr; *borrowed = true;
+      return hipSuccess;
+    }
+  }
+  return hipHostMalloc((void **)out, bytes, hipHostMallocDefault);
+}
+void pinned_return(int device, double *ptr, bool borrowed) {
+  if (!ptr) return;
+  if (borrowed) { std::lock_guard<std::mutex> lock(g_pin_mutex); g_pin[device].lent = false; }
+  else (void)hipHostFree(ptr);
+}
+
+void log_release_buffers(rgs_sim *s) {
+  dev_free(s, s->log_rec); dev_free(s, s->log_runs);
+  pinned_return(s->device, s->log_runs_host, s->log_runs_borrowed);
+  s->log_runs_host = nullptr; s->log_runs_borrowed = false;
+  s->log_cap = 0;
+}
+int log_threads(size_t n_files) {
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t t = hw == 0 ? 4 : (hw > 16 ? 16 : hw);
+  return (int)(t < n_files ? t : (n_files ? n_files : 1));
+}
+}  // namespace
+
+int rgs_log_close(rgs_sim *s) {
+  if (!s) return fail(RGS_ERR_ARG, "rgs_log_close: null handle");
+  int bad = 0;
+  for (int fd : s->log_fds) if (fd >= 0 && ::close(fd) != 0) bad = errno;
+  s->log_fds.clear();
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  log_release_buffers(s);
+  dev_free(s, s->log_ids); dev_free(s, s->log_count);
+  if (s->log_count_host) { (void)hipHostFree(s->log_count_host); s->log_count_host = nullptr; }
+  if (bad) return fail(RGS_ERR_ARG, std::string("rgs_log_close: close: ") + std::strerror(bad));
+  return RGS_OK;
+}
+
+int rgs_log_open(rgs_sim *s, int n_files, const int *arena_ids, const char *const *paths) {
+  if (!s || n_files < 1 || !arena_ids || !paths) return fail(RGS_ERR_ARG, "rgs_log_open: bad argument");
+  for (int q = 0; q < n_files; ++q)
+    if (arena_ids[q] < 0 || arena_ids[q] >= s->B || !paths[q]) return fail(RGS_ERR_ARG, "rgs_log_open: arena id out of range or null path");
+  int rc = rgs_log_close(s);                                   // like Logger::open: a log that is still open is closed first
+  if (rc != RGS_OK) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  s->log_fds.assign((size_t)n_files, -1);
+  const int T = log_threads((size_t)n_files);
+  std::vector<int> err((size_t)T, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&, t]() {
+      for (int q = t; q < n_files; q += T) {
+        const int fd = ::open(paths[q], O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);   // std::ofstream::open truncates
+        if (fd < 0) { err[(size_t)t] = errno; return; }
+        s->log_fds[(size_t)q] = fd;
+      }
+    });
+  for (auto &th : pool) th.join();
+  for (int e : err)
+    if (e) { (void)rgs_log_close(s); return fail(RGS_ERR_ARG, std::string("rgs_log_open: open: ") + std::strerror(e)); }
+  HIP_TRY(dev_alloc(s, &s->log_ids, sizeof(int) * (size_t)n_files, "log_ids"));
+  HIP_TRY(dev_alloc(s, &s->log_count, sizeof(int) * (size_t)n_files, "log_count"));
+  HIP_TRY(hipHostMalloc((void **)&s->log_count_host, sizeof(int) * (size_t)n_files, hipHostMallocDefault));
+  HIP_TRY(hipMemcpyAsync(s->log_ids, arena_ids, sizeof(int) * (size_t)n_files, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));                    // arena_ids is the caller's memory
+  return RGS_OK;
+}
+
+int rgs_step_device_log(rgs_sim *s, const double *controls_dev, int64_t step_stride, int n_steps) {
+  if (!s || !controls_dev || n_steps < 0 || step_stride < 0) return fail(RGS_ERR_ARG, "rgs_step_device_log: bad argument");
+  if (s->log_fds.empty()) return fail(RGS_ERR_ARG, "rgs_step_device_log: no log open (rgs_log_open)");
+  HIP_TRY(hipSetDevice(s->device));
+  if (n_steps == 0) return RGS_OK;
+  const int R = rgs_record_size(s->n), W = R - 1;
+  const size_t n_files = s->log_fds.size();
+  if (n_steps > s->log_cap) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    log_release_buffers(s);
+    HIP_TRY(dev_alloc(s, &s->log_rec, sizeof(double) * (size_t)n_steps * R * s->B, "log_rec"));
+    HIP_TRY(dev_alloc(s, &s->log_runs, sizeof(double) * n_files * (size_t)n_steps * W, "log_runs"));
+    HIP_TRY(pinned_borrow(s->device, sizeof(double) * n_files * (size_t)n_steps * W, &s->log_runs_host, &s->log_runs_borrowed));
+    s->log_cap = n_steps;
+  }
+  int rc = rgs_step_device_record(s, controls_dev, step_stride, n_steps, s->log_rec);
+  if (rc != RGS_OK) return rc;
+  HIP_TRY(hipMemsetAsync(s->log_count, 0, sizeof(int) * n_files, s->stream));
+  const long long items = (long long)n_files * n_steps;
+  hipLaunchKernelGGL(k_gather_runs, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s->stream, s->log_rec, s->B, R, n_steps,
+                     (int)n_files, s->log_ids, s->log_runs, s->log_count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->log_runs_host, s->log_runs, sizeof(double) * n_files * (size_t)n_steps * W, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->log_count_host, s->log_count, sizeof(int) * n_files, hipMemcpyDeviceToHost, s->stream));
+  RGS_TRY(finish(s));
+  const int T = log_threads(n_files);
+  std::vector<int> err((size_t)T, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&, t]() {
+      for (size_t q = (size_t)t; q < n_files; q += (size_t)T) {
+        const char *src = (const char *)(s->log_runs_host + q * (size_t)n_steps * W);
+        size_t left = sizeof(double) * (size_t)W * (size_t)s->log_count_host[q];
+        while (left) {
+          const ssize_t w = ::write(s->log_fds[q], src, left);
+          if (w < 0) { if (errno == EINTR) continue; err[(size_t)t] = errno; return; }
+          src += w; left -= (size_t)w;
+        }
+      }
+    });
+  for (auto &th : pool) th.join();
+  for (int e : err) if (e) return fail(RGS_ERR_ARG, std::string("rgs_step_device_log: write: ") + std::strerror(e));
+  return RGS_OK;
 }
 
 int rgs_sync(rgs_sim *s) {

@@ -12,6 +12,7 @@ All physics runs in librgs_hip.so (hand-written HIP for gfx950) through the C AB
 include/rgs_hip.h.  There is no CPU fallback.
 """
 import ctypes as C
+import os
 import struct
 
 import numpy as np
@@ -290,6 +291,41 @@ class BatchedGameSim:
             cbuf.free()
             rbuf.free()
         return out
+
+    def log_open(self, arena_ids, paths):
+        """Opens (creates / truncates) one log file per listed arena, written by the library from then on: every
+        step_device_log / run_table_logged appends the executed steps' records (29 doubles at 2v2), byte for byte the
+        reference's mc_run_<i>.log (include/utils.h:55-75, src/GameSim.cpp:160-170)."""
+        ids = np.ascontiguousarray(arena_ids, dtype=np.int32)
+        if ids.ndim != 1 or len(paths) != ids.size or ids.size == 0:
+            raise TypeError("arena_ids and paths must be equally long, non-empty lists")
+        arr = (C.c_char_p * ids.size)(*[os.fsencode(p) for p in paths])
+        _lib.check(self._L.rgs_log_open(self._h, int(ids.size), ids.ctypes.data_as(C.POINTER(C.c_int)), arr))
+
+    def step_device_log(self, controls_dev, step_stride, n_steps):
+        """step_device + log records appended to the files of log_open (one fused launch, native writer)."""
+        ptr = controls_dev.ptr if isinstance(controls_dev, _DeviceBuffer) else int(controls_dev)
+        _lib.check(self._L.rgs_step_device_log(self._h, C.c_void_p(ptr), int(step_stride), int(n_steps)))
+
+    def run_table_logged(self, table, chunk_steps=64):
+        """Step through a host control table (K, P, 2, B), uploaded in chunks, logging to the files of log_open."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        K = t.shape[0]
+        if t.shape[1:] != (self.players, 2, self.n_arenas):
+            raise TypeError("table must have shape (K, %d, 2, %d)" % (self.players, self.n_arenas))
+        stride = self.players * 2 * self.n_arenas
+        ch = max(1, min(K, chunk_steps))
+        buf = self.alloc(ch * stride)
+        try:
+            for k0 in range(0, K, ch):
+                k1 = min(K, k0 + ch)
+                buf.upload(t[k0:k1])
+                self.step_device_log(buf, stride, k1 - k0)
+        finally:
+            buf.free()
+
+    def log_close(self):
+        _lib.check(self._L.rgs_log_close(self._h))
 
     def pinned(self, shape):
         """A float64 numpy array over page-locked host memory (freed with the sim)."""

@@ -36,6 +36,9 @@ SIGNATURES = {
     "rgs_step_device_traj": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp]),
     "rgs_record_size": (C.c_int, [C.c_int]),
     "rgs_step_device_record": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
+    "rgs_log_open": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "rgs_step_device_log": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "rgs_log_close": (C.c_int, [_vp]),
     "rgs_sync": (C.c_int, [_vp]),
     "rgs_get_state": (C.c_int, [_vp, _dp]),
     "rgs_undecided": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),

@@ -136,22 +136,16 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
     N = steps_per_run(mc_params)
     mine = range(_first_run, _first_run + B)
     runs = list(mine) if logged_runs is None else [int(r) for r in logged_runs if int(r) in mine]
-    files = {}
-    if write_logs:
-        for r in runs:
-            files[r] = open(os.path.join(mc_params.log_prefix, "mc_run_{}.log".format(r)), "wb")
-    R = sim.record_size()
-
-    cols = np.array([r - _first_run for r in files], dtype=np.int64)
-    handles = list(files.values())
+    # the log files are written by the library (rgs_log_open / rgs_step_device_log): per-file gather on the device, the
+    # writes on host threads; a decided game logs nothing (cpp:121-123)
+    logging = bool(write_logs and runs)
+    if logging:
+        sim.log_open([r - _first_run for r in runs],
+                     [os.path.join(mc_params.log_prefix, "mc_run_{}.log".format(r)) for r in runs])
 
     def run(table):                                                         # table (K, P, 2, B): K steps, logged if asked for
-        if files:
-            rec = sim.run_table_recorded(table, chunk_steps=max(1, chunk_steps))      # (K, R, B): fused launches
-            per_run = np.ascontiguousarray(rec[:, :, cols].transpose(2, 0, 1))        # (n_logged, K, R): one pass over the chunk
-            ran = per_run[:, :, R - 1] != 0.0                               # a decided game logs nothing (cpp:121-123)
-            for q, f in enumerate(handles):
-                f.write(per_run[q, ran[q], :R - 1].tobytes())
+        if logging:
+            sim.run_table_logged(table, chunk_steps=max(1, chunk_steps))    # fused launches
         elif len(table) == 1:
             sim.step(table[0])
         else:
@@ -173,8 +167,8 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
             state = sim.state()
             run(np.ascontiguousarray(policy(state, k, t, seeds), dtype=np.float64)[None])
             t += mc_params.dt
-    for f in files.values():
-        f.close()
+    if logging:
+        sim.log_close()
     state = sim.state()
     out = dict(state=state, scores=state[:2].copy(), damage=sim.damage(), undecided=sim.undecided(), steps=N + 1)
     if own:

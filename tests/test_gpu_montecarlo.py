@@ -135,6 +135,49 @@ def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path, variant,
         sim.close()
 
 
+@pytest.mark.parametrize("n,chunk", [(2, 64), (2, 7), (4, 25)])
+def test_library_written_log_files_equal_the_oracles(rgp, oracle, tmp_path, n, chunk):
+    """rgs_log_open / rgs_step_device_log / rgs_log_close (the reference's Logger, include/utils.h:55-75, for a batch):
+    the files of an unordered subset of arenas are byte-identical to the oracle's logs of the same games -- games that
+    end early stop growing, a chunk boundary (7, 25) does not show, re-opening truncates, a bad path is an error."""
+    from robo_game_py import workloads as w
+    B, K = 300, 60
+    x0, _, _ = w.c2_inputs(B, n, seed=8)
+    table = w.random_hold_controls(2 * n, B, K, 10.0, hold=10, seed=n)
+    ref = oracle.batch_run(n, x0, table, K, dt=0.05, winning_score=1, n_threads=8)
+    decided = np.flatnonzero((ref["state"][0] >= 1) | (ref["state"][1] >= 1))
+    assert 4 <= decided.size < B
+    arenas = [299, 0, 17] + decided[:4].tolist()[::-1]
+    arenas = sorted(set(arenas), key=arenas.index)
+    paths = [str(tmp_path / ("lib_a%d.log" % a)) for a in arenas]
+    sim = rgp.BatchedGameSim(B, n)
+    with pytest.raises(rgp.RgsError):
+        sim.log_open([0], [str(tmp_path / "no_such_dir" / "x.log")])
+    with pytest.raises(rgp.RgsError):
+        sim.log_open([B], [paths[0]])
+    for attempt in range(2):                                      # the second pass re-opens (truncates) the same files
+        sim.reset(0.05, 1, x0)
+        sim.log_open(arenas, paths)
+        sim.run_table_logged(table, chunk_steps=chunk)
+        sim.log_close()
+    assert np.array_equal(sim.state(), ref["state"])
+    R = sim.record_size()
+    shorter = 0
+    for a, path in zip(arenas, paths):
+        opath = str(tmp_path / ("oracle_a%d.log" % a))
+        o = oracle.OracleGameSim(n)
+        o.reset(0.05, 1, x0[:, a], 0.0, True, opath)
+        for k in range(K):
+            o.run(np.ascontiguousarray(table[k, :, :, a]))
+        o.reset(0.05, 1, x0[:, a])
+        want = open(opath, "rb").read()
+        assert open(path, "rb").read() == want, "arena %d" % a
+        assert len(want) % (8 * (R - 1)) == 0
+        shorter += len(want) < 8 * (R - 1) * K
+    assert shorter > 0                                            # at least one of these games ended before the table did
+    sim.close()
+
+
 def test_recorded_steps_with_noise(rgp, oracle, tmp_path):
     """noise > 0 (host-tape wave kernel, one step per launch): the in-kernel records still equal the reference's log."""
     from robo_game_py import workloads as w
