@@ -194,15 +194,21 @@ int rgs_debug_inject_pool_timeout(rgs_sim *sim);
 int rgs_set_variant(rgs_sim *sim, int variant);
 
 /* noise != 0 (w_stdev_, src/GameSim.cpp:30,66-67), two modes, chosen BEFORE rgs_reset:
- *   0 (default) exact: the draws come from the reference's own std::default_random_engine / std::normal_distribution
- *     on the host (tapes, <= 4096 arenas per handle, one launch per step): bit-identical to the reference;
+ *   0 host tapes: the draws come from the reference's own std::default_random_engine / std::normal_distribution on the
+ *     host (<= 4096 arenas per handle, one launch per step): bit-identical to the reference;
  *   1 device generator: the same engine (minstd_rand0, integer, bit-exact), the same generate_canonical and the same
- *     Marsaglia polar method run on the GPU (csrc/gsim_rng.hpp), normals in the reference's order; only log() is
- *     the device's, so the normals agree with the host's to ~1 ulp and a noisy game matches the reference
- *     statistically, not bit for bit.  Any batch size, fused launches.
+ *     Marsaglia polar method run on the GPU (csrc/gsim_rng.hpp), normals in the reference's order.  Any batch size, fused
+ *     launches.  Where rgs_noise_is_exact() = 1 (below) its log() is the host's too and the mode is bit-identical to the
+ *     reference like mode 0 -- it is then the DEFAULT; otherwise log() is the device library's, the normals agree with the
+ *     host's to ~1 ulp, a noisy game matches the reference statistically, and mode 0 is the default.
  * rgs_selftest_rng: the device generator's first n (<= 4096) normals for a seed and the canonical uniforms of its first
  * n_attempts polar attempts, for comparison with the host's <random>. */
 int rgs_set_noise_mode(rgs_sim *sim, int mode);
+/* 1 if this build's device generator uses the HOST's log() (glibc's table-driven log restated in csrc/gsim_hostlog.hpp
+ * with the constants of the installed libm.so.6, accepted at build time only if bit-identical to the host's log() on 3e7
+ * arguments): the normals are then std::normal_distribution's bit for bit and noise mode 1 reproduces the reference's
+ * noisy trajectories exactly at any batch size.  0: the device library's log (normals within 2 ulp, statistical parity). */
+int rgs_noise_is_exact(void);
 int rgs_selftest_rng(int device_id, long long seed, int n, int n_attempts, double *normals_host, double *canonicals_host,
                      uint32_t *x_end, int *have);
 

@@ -56,6 +56,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
   constexpr int WIN = rng_window<N>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long a = (long long)blockIdx.x * kWavesPerBlock + wave;
+  double *const logtab = lds + kWavesPerBlock * (L::DOUBLES + WIN);
+  DevRng::load_log_table(logtab, threadIdx.x, 64 * kWavesPerBlock);
+  __syncthreads();
   if (a >= p.B) return;
   double *mine = lds + wave * (L::DOUBLES + WIN);
   const GridView<N, false> G{mine, nullptr GSIM_GRID_DBG(p)};
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
   rng.x = p.rng_x[a];
   rng.have = p.rng_left_n[a];
   rng.lane_jump = DevRng::lcg_pow_lane(lane);
+  rng.logtab = logtab;
   for (int i = lane; i < rng.have; i += 64) rng.buf[i] = p.rng_left[a * kRngLeft + i];
   wave_sync();
   for (int k = 0; k < p.n_steps; ++k) {

@@ -15,20 +15,24 @@
 // stream reads outputs 4i+1 .. 4i+4: their positions are known in advance and the engine can jump (x_{n+k} = a^k x_n mod
 // m).  The 64 lanes of a wavefront therefore evaluate 64 consecutive attempts at once, a ballot compacts the accepted
 // ones in order, and the stream of normals comes out in exactly the reference's order.  Every integer step and every
-// +, *, / and sqrt is the reference's (IEEE, same association); only log() is the device's (ocml, <= 1 ulp from
-// glibc's), so the normals agree with the host's to within 2 ulp and a noisy trajectory matches the reference
-// STATISTICALLY, not bit for bit (chaotic dynamics).  The exact mode -- host-drawn tapes -- stays the default.
+// +, *, / and sqrt is the reference's (IEEE, same association).  log() is the HOST's: gsim_hostlog.hpp restates glibc's
+// table-driven log with the constants of the installed libm.so.6 and is accepted at build time only if it reproduces the
+// host's log() bit for bit (GSIM_HOST_LOG = 1); the normals are then the reference's bit for bit and so is every noisy
+// trajectory, at any ensemble size (rgs_noise_is_exact() = 1).  Where that check does not pass (another C library), the
+// device library's log is used (<= 1 ulp from glibc's): normals within 2 ulp, noisy trajectories match STATISTICALLY only.
 //
 // All RK4 calls of a player consume 8 draws, an even number: between calls the distribution never holds a cached second
 // value, so the generator's whole state between steps is the engine's x (plus, here, the normals a wavefront generated
 // ahead but has not consumed yet, which are kept in order and consumed first).
 #pragma once
 #include "gsim_common.hpp"
+#include "gsim_hostlog.hpp"
 
 namespace gsim {
 
 constexpr unsigned kLcgA = 16807u, kLcgM = 2147483647u;      // minstd_rand0
 constexpr int kRngSlack = 256;                               // room for one iteration's overshoot (<= 128) plus what a step leaves unconsumed
+constexpr int kLogTabDoubles = 256;                          // the host log's {1/c, log c} table, kept in LDS by the kernels that draw
 constexpr int kRngLeft = 256;                                // normals an arena may carry from one launch to the next (global memory)
 template <int N>
 constexpr int rng_window() { return 80 * 2 * N + kRngSlack; }   // doubles of LDS per arena: ten columns' draws of all players (an event's blocks need less)
@@ -74,6 +78,7 @@ struct DevRng {
   int cap, have;
   unsigned x;
   unsigned lane_jump;                                                            // a^(4 lane) mod m, set once per kernel
+  const double *logtab;                                                          // LDS copy of the host log's table (load_log_table)
 
   // Appends normals until at least `need` are buffered (need + 128 <= cap; the callers keep need <= cap - kRngSlack).
   __device__ __forceinline__ void ensure(int need, int lane) {
@@ -87,7 +92,12 @@ struct DevRng {
       const bool ok = !(r2 > 1.0 || r2 == 0.0);
       const unsigned long long m = __ballot(ok);
       if (ok) {
-        const double mult = sqrt_ieee(div_ieee(-2.0 * ::log(r2), r2));   // random.tcc:1826
+#if GSIM_HOST_LOG
+        const double lg = host_log(r2, logtab);                                  // the host's log(), bit for bit (gsim_hostlog.hpp)
+#else
+        const double lg = ::log(r2);                                             // the device library's: <= 1 ulp from the host's
+#endif
+        const double mult = sqrt_ieee(div_ieee(-2.0 * lg, r2));                  // random.tcc:1826
         const int at = have + 2 * __builtin_popcountll(m & ((1ull << lane) - 1ull));
         buf[at] = vy * mult;                                                     // returned first (:1829)
         buf[at + 1] = vx * mult;                                                 // the cached value, returned by the next call (:1827)
@@ -110,6 +120,13 @@ struct DevRng {
     for (int q = 0; q < 4; ++q) if (lane + 64 * q < rest) buf[lane + 64 * q] = keep[q];
     have = rest;
     wave_sync();
+  }
+
+  // Copies the host log's table into LDS (256 doubles at dst); every thread of the block calls it, then synchronises.
+  __device__ static __forceinline__ void load_log_table(double *dst, int tid, int nthreads) {
+#if GSIM_HOST_LOG
+    for (int i = tid; i < kLogTabDoubles; i += nthreads) dst[i] = kHostLogTabDev[i];
+#endif
   }
 
   __device__ static __forceinline__ unsigned lcg_pow_lane(int lane) {            // a^(4 lane) mod m

@@ -59,6 +59,23 @@ __device__ __forceinline__ Chain rk4_dyn(Chain x, double u, double coef, double 
   return rk4_axis<0>(x, u, coef, tau, inv, h);
 }
 
+// rk4_axis_noise with the division flavour chosen at run time like rk4_dyn (device-generator kernel).  The same window
+// applies: for the puck (no noise, its velocity decays) fast_division_safe covers the sub-steps of one ten-column block; a
+// player's velocity, re-drawn at every stage, cannot come closer to zero than ~sigma * 2^-130 without being zero, and the
+// host only selects FAST != 0 for 2^-300 <= sigma <= 2^300 (launch_steps), so the check at the block's first column holds
+// for all of it.
+template <int FAST>
+__device__ __forceinline__ Chain rk4_noise_dyn(Chain x, double u, double coef, double tau, double h, double sigma,
+                                               const double *nz, double inv, bool fast) {
+#ifdef GSIM_NOISE_NO_GUARD                                   // A/B only: what the run-time choice costs
+  return rk4_axis_noise<FAST>(x, u, coef, tau, h, sigma, nz, inv);
+#endif
+  if (FAST != 0) {
+    if (fast) return rk4_axis_noise<FAST>(x, u, coef, tau, h, sigma, nz, inv);
+  }
+  return rk4_axis_noise<0>(x, u, coef, tau, h, sigma, nz);
+}
+
 template <int GW>
 __device__ __forceinline__ unsigned long long group_ballot(bool pred, int gbase) {
   unsigned long long m = __ballot(pred);
@@ -549,10 +566,19 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     for (int i0 = 1; i0 <= kGrid; i0 += FB) {
       rng->ensure(8 * FB * L::P, gbase + lg);
       if (chain) {
-        for (int i = i0; i < i0 + FB; ++i) {
-          x = rk4_axis_noise<FAST>(x, u, coef, tau, dt_col, sg, tape + 8 * ((i - i0) * L::P + (e != PK ? e : 0)) + ax, inv);
-          G.pos(i, e, ax) = x.p;
-          G.vel(i, e, ax) = x.v;
+        // the division flavour is chosen once per block, outside the column loop (inside it costs 9 % of the kernel)
+        if (FAST != 0 && fast_division_safe(u, x.v)) {
+          for (int i = i0; i < i0 + FB; ++i) {
+            x = rk4_axis_noise<FAST>(x, u, coef, tau, dt_col, sg, tape + 8 * ((i - i0) * L::P + (e != PK ? e : 0)) + ax, inv);
+            G.pos(i, e, ax) = x.p;
+            G.vel(i, e, ax) = x.v;
+          }
+        } else {
+          for (int i = i0; i < i0 + FB; ++i) {
+            x = rk4_axis_noise<0>(x, u, coef, tau, dt_col, sg, tape + 8 * ((i - i0) * L::P + (e != PK ? e : 0)) + ax);
+            G.pos(i, e, ax) = x.p;
+            G.vel(i, e, ax) = x.v;
+          }
         }
       }
       rng->consume(8 * FB * L::P, gbase + lg);
@@ -753,17 +779,18 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     const int slot = (is_pair && !el.first && ci != PK) ? 1 : 0;
     const double sg = (NOISE && el.d != PK) ? p.sigma : 0.0;
     int call = 0;                                            // this disc's RK4 calls so far in this event
-    auto noisy = [&](Chain xx, double hh) {
+    auto noisy = [&](Chain xx, double hh, bool usefast) {       // usefast: this chain's magnitudes are in div_tau's window (device generator only)
       const int c0 = cur + 8 * (call * np + slot);
       ++call;
-      return rk4_axis_noise<NOISE == 2 ? FAST : 0>(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax, el.inv);
+      return rk4_noise_dyn<NOISE == 2 ? FAST : 0>(xx, el.u, el.coef, el.tau, hh, sg, tape + (c0 < tape_last ? c0 : tape_last) + el.ax, el.inv,
+                                                  usefast);
     };
     if (NOISE == 2) rng->ensure(8 * np * 2, gbase + lg);     // the draws of the two RK4 calls around the impact (cur == 0: the window starts at them)
     if (lg < 4) {
       x.p = G.pos(base - 1, el.d, el.ax);
       x.v = G.vel(base - 1, el.d, el.ax);
       fast = FAST != 0 && fast_division_safe(el.u, x.v);
-      if (NOISE) x = noisy(x, dt_t); else
+      if (NOISE) x = noisy(x, dt_t, fast); else
       x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_t, fast);   // cpp:255-256, 309
 
       if (is_pair) {                                         // cpp:242-282
@@ -806,7 +833,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
       if (goal) {
         x.p = 0.0; x.v = 0.0;                                // cpp:325
       } else if (NOISE) {
-        x = noisy(x, dt_col - dt_t);
+        x = noisy(x, dt_col - dt_t, fast);
       } else {
         x = rk4_dyn<FAST>(x, el.u, el.coef, el.tau, el.inv, dt_col - dt_t, fast);   // cpp:287-288, 331
       }
@@ -840,9 +867,16 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
         rng->ensure(8 * np * (g1 - g0 + 1), gbase + lg);
         call = 0;
         if (lg < 4) {
-          for (int g = g0; g <= g1; ++g) {
-            x = noisy(x, dt_col);                            // cpp:294-295, 338
-            fix_store_column<N, SPLITV>(el, G, x, g, true);
+          if (FAST != 0 && fast_division_safe(el.u, x.v)) {    // holds for the block's ten columns; chosen outside the loop
+            for (int g = g0; g <= g1; ++g) {
+              x = noisy(x, dt_col, true);                      // cpp:294-295, 338
+              fix_store_column<N, SPLITV>(el, G, x, g, true);
+            }
+          } else {
+            for (int g = g0; g <= g1; ++g) {
+              x = noisy(x, dt_col, false);
+              fix_store_column<N, SPLITV>(el, G, x, g, true);
+            }
           }
         }
         rng->consume(8 * np * (g1 - g0 + 1), gbase + lg);
@@ -851,7 +885,7 @@ __device__ unsigned arena_step_group(const StepArgs &p, const double *__restrict
     } else if (NOISE && base < kGrid) {                      // host tape: the whole remainder in the reference's call order
       if (lg < 4) {
         for (int g = base + 1; g <= kGrid; ++g) {
-          x = noisy(x, dt_col);                              // cpp:294-295, 338
+          x = noisy(x, dt_col, false);                       // cpp:294-295, 338
           fix_store_column<N, SPLITV>(el, G, x, g, true);
         }
       }

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64) void k_selftest_rng(unsigned x0, int n, int n_a
     canonicals[2 * i + 1] = lcg_canonical(d3, d4);
   }
   DevRng rng;
+  rng.logtab = lds + n + kRngSlack;
+  DevRng::load_log_table(lds + n + kRngSlack, lane, 64);
+  wave_sync();
   rng.buf = lds; rng.cap = n + kRngSlack; rng.x = x0; rng.have = 0; rng.lane_jump = DevRng::lcg_pow_lane(lane);
   rng.ensure(n, lane);
   for (int i = lane; i < n; i += 64) normals[i] = rng.buf[i];
@@ -265,7 +268,9 @@ struct rgs_sim {
   bool log_runs_borrowed = false;
   int *log_count_host = nullptr;
   int log_cap = 0;                                   // steps the chunk buffers hold
-  int noise_mode = 0;              // rgs_set_noise_mode: 0 = exact (host tapes), 1 = device generator (statistical parity)
+  // rgs_set_noise_mode: 0 = draws from the host's <random> (tapes), 1 = the same generator on the device; 1 is the default
+  // where it is exact as well (built with the host's log, gsim_hostlog.hpp)
+  int noise_mode = GSIM_HOST_LOG ? 1 : 0;
   unsigned *rng_x = nullptr;       // device generator: engine state, left-over count and left-over normals per arena
   int *rng_left_n = nullptr;
   double *rng_left = nullptr;
@@ -656,7 +661,10 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
     a.rng_x = s->rng_x; a.rng_left_n = s->rng_left_n; a.rng_left = s->rng_left;
     // division by the taus as in the noise-free wave kernel (the reciprocal forms equal '/' inside their magnitude window; this
     // mode is statistical anyway, rgs_set_fast_division(0) forces IEEE)
-    return launch_kind(s, a, LAUNCH_WAVE_RNG, !use_fast_division(s) ? 0 : (s->one_step_ok ? 3 : 1));
+    // (with the host's log the draws are the reference's bit for bit, gsim_hostlog.hpp, so the division has to be exact as
+    // well: the reciprocal forms only inside their window, which for a noisy player needs a sigma of ordinary size)
+    const bool sigma_ok = std::fabs(s->sigma) >= 0x1p-300 && std::fabs(s->sigma) <= 0x1p300;
+    return launch_kind(s, a, LAUNCH_WAVE_RNG, !(use_fast_division(s) && sigma_ok) ? 0 : (s->one_step_ok ? 3 : 1));
   }
   if (s->sigma != 0.0) {                                       // noise: tape-driven wave kernel, one step per launch
     for (int k = 0; k < n_steps; ++k) {
@@ -878,7 +886,7 @@ int rgs_reset(rgs_sim *s, double dt, int winning_score, const double *x0_ball_ho
     HIP_TRY(hipStreamSynchronize(s->stream));                  // x0 goes out of scope
   } else if (noise != 0.0) {
     if (s->B > kNoiseMaxArenas)
-      return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 in the exact mode needs host-generated draw tapes and is limited to 4096 arenas per handle (rgs_set_noise_mode(sim, 1) has no limit)");
+      return fail(RGS_ERR_UNSUPPORTED, "rgs_reset: noise != 0 with host-generated draw tapes (rgs_set_noise_mode 0) is limited to 4096 arenas per handle; the device generator (mode 1) has no limit");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->bak_state) {
       HIP_TRY(dev_alloc(s, &s->bak_state, sizeof(double) * s->S * s->B, "bak_state"));
@@ -1335,8 +1343,12 @@ int rgs_set_variant(rgs_sim *s, int variant) {
   return RGS_OK;
 }
 
+// 1: the device generator's log() is the host's, bit for bit (gsim_hostlog.hpp accepted at build time): noise mode 1 then
+// reproduces the reference's draws and trajectories exactly; 0: the device library's log, statistical parity only.
+int rgs_noise_is_exact(void) { return GSIM_HOST_LOG ? 1 : 0; }
+
 int rgs_set_noise_mode(rgs_sim *s, int mode) {
-  if (!s || (mode != 0 && mode != 1)) return fail(RGS_ERR_ARG, "rgs_set_noise_mode: mode must be 0 (exact, host tapes) or 1 (device generator)");
+  if (!s || (mode != 0 && mode != 1)) return fail(RGS_ERR_ARG, "rgs_set_noise_mode: mode must be 0 (host tapes) or 1 (device generator)");
   s->noise_mode = mode;                                        // takes effect at the next rgs_reset (the engines are seeded there)
   return RGS_OK;
 }
@@ -1353,7 +1365,7 @@ int rgs_selftest_rng(int device_id, long long seed, int n, int n_attempts, doubl
   HIP_TRY(scratch.alloc(&nd, sizeof(double) * n));
   HIP_TRY(scratch.alloc(&cd, sizeof(double) * 2 * (size_t)n_attempts));
   HIP_TRY(scratch.alloc(&misc, 16));
-  hipLaunchKernelGGL(k_selftest_rng, dim3(1), dim3(64), sizeof(double) * (n + kRngSlack), 0, lcg_seed(seed), n, n_attempts, nd, cd,
+  hipLaunchKernelGGL(k_selftest_rng, dim3(1), dim3(64), sizeof(double) * (n + kRngSlack + kLogTabDoubles), 0, lcg_seed(seed), n, n_attempts, nd, cd,
                      (unsigned *)misc, (int *)misc + 1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(normals_host, nd, sizeof(double) * n, hipMemcpyDeviceToHost));

@@ -59,7 +59,7 @@ hipError_t launch_hybrid2_mode(const StepArgs &args, hipStream_t stream) {
 template <int FAST>
 hipError_t launch_wave_rng(const StepArgs &args, hipStream_t stream) {
   const long long blocks = (args.B + kWavesPerBlock - 1) / kWavesPerBlock;
-  const size_t lds = sizeof(double) * (WaveLayout<N>::DOUBLES + rng_window<N>()) * kWavesPerBlock;
+  const size_t lds = sizeof(double) * ((WaveLayout<N>::DOUBLES + rng_window<N>()) * kWavesPerBlock + kLogTabDoubles);
   static std::atomic<unsigned long long> attr_set{0ull};      // > 64 KB of dynamic LDS at the large team sizes: per device, see launch_pool_mode
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);

@@ -412,10 +412,17 @@ class BatchedGameSim:
         _lib.check(self._L.rgs_set_variant(self._h, int(variant)))
 
     def set_noise_mode(self, mode):
-        """How noise != 0 is drawn, from the next reset() on: "exact" (default: the reference's <random> on the host,
-        bit-identical, <= 4096 arenas) or "device" (the same generator on the GPU, statistical parity, no limit)."""
-        m = {"exact": 0, "device": 1, 0: 0, 1: 1}[mode]
+        """How noise != 0 is drawn, from the next reset() on: "host" (the reference's <random> on the host: draw tapes,
+        <= 4096 arenas, one launch per step) or "device" (the same generator on the GPU: any batch size, fused launches).
+        Both are bit-identical to the reference where noise_is_exact() (the library was built with the host's log());
+        "device" is then the default.  Otherwise "device" is statistical and "host" the default.  ("exact" = "host".)"""
+        m = {"host": 0, "exact": 0, "device": 1, 0: 0, 1: 1}[mode]
         _lib.check(self._L.rgs_set_noise_mode(self._h, m))
+
+    @staticmethod
+    def noise_is_exact():
+        """True if the device noise generator reproduces the reference's draws bit for bit (rgs_noise_is_exact)."""
+        return bool(_lib.lib().rgs_noise_is_exact())
 
     def set_rebalance(self, enable):
         """Pooled variants: deal arenas in lasting contact evenly over the workgroups between fused launches (default on)."""

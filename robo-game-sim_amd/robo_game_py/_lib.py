@@ -66,6 +66,7 @@ SIGNATURES = {
     "rgs_debug_inject_pool_timeout": (C.c_int, [_vp]),
     "rgs_set_variant": (C.c_int, [_vp, C.c_int]),
     "rgs_set_noise_mode": (C.c_int, [_vp, C.c_int]),
+    "rgs_noise_is_exact": (C.c_int, []),
     "rgs_selftest_rng": (C.c_int, [C.c_int, C.c_longlong, C.c_int, C.c_int, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "rgs_set_rebalance": (C.c_int, [_vp, C.c_int]),
     "rgs_get_heat": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),

@@ -91,7 +91,7 @@ def mindless_policy(state, k, t, seeds):
 mindless_policy.open_loop = True
 
 
-NOISE_MAX_ARENAS = 4096      # include/rgs_hip.h: noise != 0 needs host-generated draw tapes, <= 4096 arenas per handle
+NOISE_MAX_ARENAS = 4096      # include/rgs_hip.h: noise != 0 from host-generated draw tapes: <= 4096 arenas per handle
 
 
 def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=0, write_logs=True, logged_runs=None,
@@ -104,12 +104,13 @@ def monte_carlo_batched(mc_params, policy=mindless_policy, n_per_team=2, device=
     A policy marked `open_loop = True` (its commands ignore the state's values: mindless_policy) is evaluated for
     chunk_steps steps ahead and each chunk runs as one fused launch, log records included; any other policy is closed
     loop: one step, one state download per step, like the reference (py/MonteCarlo.py:36-45).
-    With noise_stdev != 0 an ensemble of more than 4096 runs is stepped in chunks of 4096 (one handle each,
-    the stepper's limit for host-generated noise tapes); run i keeps seed i either way.
+    With noise_stdev != 0 the draws come from the device generator where that is exact (BatchedGameSim.noise_is_exact():
+    any ensemble size, fused launches); otherwise from host-generated tapes, and an ensemble of more than 4096 runs is
+    stepped in chunks of 4096 (one handle each, the tapes' limit); run i keeps seed i either way.
     Returns dict(state (S, B), scores (2, B), damage (P, P, B), undecided (B,), steps).
     """
     B = int(mc_params.num_runs)
-    if float(mc_params.noise_stdev) != 0.0 and B > NOISE_MAX_ARENAS and sim is None:
+    if float(mc_params.noise_stdev) != 0.0 and B > NOISE_MAX_ARENAS and sim is None and not BatchedGameSim.noise_is_exact():
         import copy
         if _write_config:
             write_configuration(mc_params)

@@ -178,13 +178,18 @@ def test_library_written_log_files_equal_the_oracles(rgp, oracle, tmp_path, n, c
     sim.close()
 
 
-def test_recorded_steps_with_noise(rgp, oracle, tmp_path):
-    """noise > 0 (host-tape wave kernel, one step per launch): the in-kernel records still equal the reference's log."""
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_recorded_steps_with_noise(rgp, oracle, tmp_path, mode):
+    """noise > 0 (host-tape wave kernel, one step per launch; device generator, fused launches): the in-kernel records
+    still equal the reference's log."""
     from robo_game_py import workloads as w
+    if mode == "device" and not rgp.BatchedGameSim.noise_is_exact():
+        pytest.skip("built without the host's log tables: the device noise mode is statistical")
     n, B, K = 2, 12, 40
     x0, _, _ = w.c2_inputs(B, n, seed=18)
     table = w.random_hold_controls(2 * n, B, K, 8.0, hold=8, seed=5)
     sim = rgp.BatchedGameSim(B, n)
+    sim.set_noise_mode(mode)
     sim.reset(0.05, 2, x0, 0.3, False, "", 11)
     rec = sim.run_table_recorded(table, chunk_steps=16)
     R = sim.record_size()

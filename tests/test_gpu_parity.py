@@ -379,11 +379,17 @@ def test_full_size_batch_is_shard_invariant(rgp):
         sub.close()
 
 
-def test_noise_matches_reference_generator_single_game(rgp, oracle):
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_noise_matches_reference_generator_single_game(rgp, oracle, mode):
     """noise > 0 through the drop-in GameSim: same libstdc++ engine/distribution stream, consumed in the
-    reference's call order (fill, then every re-integration), incl. the w_dist_ that survives reset()."""
+    reference's call order (fill, then every re-integration), incl. the w_dist_ that survives reset().  Both sources of
+    the draws: the host's <random> (tapes) and the generator on the device (one step per launch here: draws generated
+    ahead are carried from call to call and dropped by reset)."""
+    if mode == "device" and not rgp.BatchedGameSim.noise_is_exact():
+        pytest.skip("built without the host's log tables: the device noise mode is statistical")
     Z = np.zeros(2)
     g, o = rgp.GameSim(), oracle.OracleGameSim()
+    g._b.set_noise_mode(mode)
     rng = np.random.default_rng(3)
     for seed, noise, x0 in ((7, 0.3, [0.5, 0.2, 3.0, 1.0]), (11, 2.0, [-2.0, 1.0, -4.0, 2.0]), (0, 0.05, [0, 0, 0, 0])):
         sg = g.reset(0.05, 3, np.array(x0, dtype=float), noise, False, "", seed, 0.1, 0.5, 1.0, 0.5)
@@ -397,14 +403,19 @@ def test_noise_matches_reference_generator_single_game(rgp, oracle):
     assert o.stats()["resolved"] > 10                       # collisions happened, so re-integration draws were used
 
 
+@pytest.mark.parametrize("mode", ["host", "device"])
 @pytest.mark.parametrize("n", [2, 4])
-def test_noise_batched_with_many_events(rgp, oracle, n):
+def test_noise_batched_with_many_events(rgp, oracle, n, mode):
     """Batched noise: arena a uses seed + a; chase play forces steps with more events than the first,
-    short draw tape holds, which exercises the redo-with-a-longer-tape path."""
+    short draw tape holds, which exercises the redo-with-a-longer-tape path (host tapes) and 49-event steps whose
+    re-integrations draw block after block (device generator)."""
     from robo_game_py import workloads as w
+    if mode == "device" and not rgp.BatchedGameSim.noise_is_exact():
+        pytest.skip("built without the host's log tables: the device noise mode is statistical")
     B, K, dt = 48, 80, 0.05
     x0, _, _ = w.c2_inputs(B, n, seed=9)
     sim = rgp.BatchedGameSim(B, n)
+    sim.set_noise_mode(mode)
     state = sim.reset(dt, 3, x0, 0.4, False, "", 100, 0.1, 0.5, 1.0, 0.5)
     osims = [oracle.OracleGameSim(n) for _ in range(B)]
     for a, o in enumerate(osims):
@@ -543,6 +554,7 @@ def test_auto_variant_switches_in_sustained_contact(rgp, oracle):
 
 def test_noise_is_limited_not_faked(rgp):
     sim = rgp.BatchedGameSim(5000, 2)
+    sim.set_noise_mode("host")                                     # draw tapes from the host's <random>: <= 4096 arenas
     with pytest.raises(rgp.RgsError):
         sim.reset(0.05, 3, np.zeros(4), 0.1)
     sim.close()
@@ -787,7 +799,39 @@ def test_device_noise_generator_reproduces_the_hosts_random(rgp, oracle, seed):
     assert np.array_equal(canon.view(np.uint64), want_c.view(np.uint64))
     ulp = np.abs(normals.view(np.int64) - want_n.view(np.int64))
     assert np.sign(normals).tolist() == np.sign(want_n).tolist() and ulp.max() <= 2, ulp.max()
+    if rgp._lib.lib().rgs_noise_is_exact():                        # built with the host's log (csrc/gsim_hostlog.hpp):
+        assert np.array_equal(normals.view(np.uint64), want_n.view(np.uint64))   # std::normal_distribution's draws bit for bit
     assert have.value >= n
+
+
+@pytest.mark.parametrize("n,B,K", [(2, 6000, 60), (4, 1500, 40), (1, 1000, 80)])
+def test_device_noise_mode_is_bit_identical_to_the_reference_draws(rgp, oracle, n, B, K):
+    """With the host's log() restated on the device (rgs_noise_is_exact) the device generator IS the reference's
+    std::default_random_engine + std::normal_distribution: noisy games -- collisions, goals, re-integrations that consume
+    draws out of column order, launch boundaries with draws generated ahead, more arenas than the host-tape mode takes --
+    end in the oracle's states, damage and event counts bit for bit."""
+    from robo_game_py import workloads as w
+    if not rgp._lib.lib().rgs_noise_is_exact():
+        pytest.skip("built without the host's log tables: the device noise mode is statistical")
+    dt, sigma = 0.05, 0.3
+    x0, amp, ph = w.c2_inputs(B, n, seed=90 + n)
+    x0 = x0 * np.array([0.4, 0.4, 0.5, 0.5])[:, None]
+    x0[:, ::5] = np.array([4.0, 0.1, 8.0, 0.0])[:, None]           # every fifth puck is shot at the right goal
+    x0[2:, 1::7] = np.array([1e-200, -3e-250])[:, None]            # pucks below the reciprocal division's window: IEEE '/' there
+    table = w.circle_controls(amp * 1.5, ph, w.step_times(K, dt))
+    ref = oracle.batch_run(n, x0, table, K, dt=dt, winning_score=2, noise=sigma, seed_base=17, n_threads=8, want_damage=True)
+    sim = rgp.BatchedGameSim(B, n)
+    sim.set_noise_mode("device")
+    sim.reset(dt, 2, x0, sigma, False, "", 17)
+    sim.run_table(table[:7], chunk_steps=7)
+    got = sim.run_table(table[7:], chunk_steps=K - 7)
+    c = sim.counters()
+    assert_same(got, ref["state"], "device noise, n=%d" % n)
+    P = 2 * n
+    assert_same(sim.damage().reshape(P * P, B), ref["damage"], "damage")
+    assert c["resolved"] == ref["stats"]["resolved"] and c["cap_hits"] == ref["stats"]["cap_hits"]
+    assert ref["stats"]["resolved"] > B and (ref["state"][:2] > 0).any()      # collisions and goals happened
+    sim.close()
 
 
 def test_device_noise_mode_statistics_and_scale(rgp, oracle):
@@ -818,6 +862,7 @@ def test_device_noise_mode_statistics_and_scale(rgp, oracle):
     assert got[:, 0].tolist() != got[:, 1].tolist()                       # different seeds, different games
     sim.close()
     big = rgp.BatchedGameSim(20000, n)                                    # (c)
+    big.set_noise_mode("host")
     with pytest.raises(rgp.RgsError):
         big.reset(dt, 1000, x0[:, :1].repeat(20000, axis=1), sigma, False, "", 5)
     big.set_noise_mode("device")
