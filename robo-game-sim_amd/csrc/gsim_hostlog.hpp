@@ -21,7 +21,10 @@
 //
 // Only finite, positive, normal x (what the polar method passes: 0 < r2 <= 1): no special cases.
 #pragma once
-#include "host_log_tables.h"
+#ifndef GSIM_HOST_LOG_TABLES_H                               // (the build step checks candidate headers by their full path)
+#define GSIM_HOST_LOG_TABLES_H "host_log_tables.h"
+#endif
+#include GSIM_HOST_LOG_TABLES_H
 #ifdef GSIM_FORCE_DEVICE_LOG                                 // A/B and fall-back testing: build as if no table had been accepted
 #undef GSIM_HOST_LOG
 #define GSIM_HOST_LOG 0
