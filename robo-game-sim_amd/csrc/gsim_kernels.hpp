@@ -49,8 +49,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
 // One wavefront per arena with the reference's noise generator ON THE DEVICE (gsim_rng.hpp): n_steps fused steps per
 // launch, any number of arenas; statistical parity with the reference (the exact mode is k_step_wave<.., NOISE = 1> fed
 // with host-drawn tapes).
+#ifndef GSIM_RNG_WAVES
+#define GSIM_RNG_WAVES GSIM_WAVE_WAVES                       // wavefronts per SIMD of the device-noise kernel (0: the compiler's choice)
+#endif
+#if GSIM_RNG_WAVES > 0
+#define GSIM_RNG_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GSIM_RNG_WAVES, GSIM_RNG_WAVES)))
+#else
+#define GSIM_RNG_OCCUPANCY
+#endif
 template <int N, int FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_step_wave_rng(StepArgs p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_RNG_OCCUPANCY void k_step_wave_rng(StepArgs p) {
   extern __shared__ double lds[];
   using L = WaveLayout<N>;
   constexpr int WIN = rng_window<N>();
