@@ -89,6 +89,11 @@ def parse_args(argv=None):
                     "(default: arenas x ranks + offset)")
     ap.add_argument("--no-rebalance", action="store_true", help="diagnostic: pooled variants keep every arena on its own workgroup")
     ap.add_argument("--dt", type=float, default=None, help="diagnostic / tools/sweep.py: override the preset's step length")
+    ap.add_argument("--noise", type=float, default=0.0,
+                    help="w_stdev_ of the players' dynamics (src/GameSim.cpp:66-67; not a BASELINE config, one rank only): the "
+                         "reference's generator runs on the device, arena a seeded --noise-seed + a like cpp:41; the sampled arenas "
+                         "are checked against the oracle's <random> draws")
+    ap.add_argument("--noise-seed", type=int, default=1)
     args = ap.parse_args(argv)
     preset = PRESETS[args.config]
     if args.n_per_team is None:
@@ -217,6 +222,8 @@ def main():
     S = rgp.state_size(n)
     dev = torch.device("cuda", local_rank)
     lo, hi = args.arena_offset + rank * B, args.arena_offset + (rank + 1) * B
+    if args.noise != 0.0 and world > 1:
+        raise SystemExit("bench.py --noise: one rank only (the sampled arenas of the last rank would need their own seed base)")
     total_ensemble = args.ensemble_arenas if args.ensemble_arenas > 0 else B * world + args.arena_offset
 
     # ---- inputs, resident in HBM before timing ------------------------------------------
@@ -270,11 +277,17 @@ def main():
         torch.cuda.synchronize()
         sim.sync()
 
+    def reset():
+        if args.noise != 0.0:
+            sim.reset(DT, WIN, np.ascontiguousarray(x0), args.noise, False, "", args.noise_seed + lo)
+        else:
+            sim.reset(DT, WIN, np.ascontiguousarray(x0))
+
     if W == 0:                                                 # no warm-up steps: load the kernels / wake the clocks on a scratch run
-        sim.reset(DT, WIN, np.ascontiguousarray(x0))
+        reset()
         run_steps(0, min(K, 8))
         sim.sync()
-    sim.reset(DT, WIN, np.ascontiguousarray(x0))
+    reset()
     if args.stamps:
         sim.stamps(True)
         sim.wave_log()                                         # arm the per-wavefront log (asynchronous pool)
@@ -418,7 +431,8 @@ def main():
         from oracle import oracle as orc
         nc = cs0 + cs1
         cores = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
-        ref = orc.batch_run(n, x0s, sub, W + K, dt=DT, winning_score=WIN, n_threads=cores)
+        ref = orc.batch_run(n, x0s, sub, W + K, dt=DT, winning_score=WIN, n_threads=cores, noise=args.noise,
+                            seed_base=args.noise_seed + lo)
         delta = float(np.max(np.abs(got - ref["state"])))
         import hashlib
         sha = lambda arr: hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
@@ -447,7 +461,9 @@ def main():
             "ms_per_step": round(elapsed * 1e3 / K, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d parallel %dv%d arenas per GPU, dt=%g, winning_score=%d, %s"
-                                   % (args.config.upper(), B, n, n, DT, WIN, controls),
+                                   % (args.config.upper(), B, n, n, DT, WIN, controls)
+                                   + ("" if args.noise == 0.0 else ", noise %g (generator on the device, %s)" % (
+                                       args.noise, "exact" if rgp.BatchedGameSim.noise_is_exact() else "statistical parity")),
                        "arenas_per_gpu": B, "n_per_team": n, "steps_per_launch": args.steps_per_launch,
                        "variant": args.variant, "parallelism": "arena-sharded x%d, end-of-run all-gather" % world},
             "collective": None if world == 1 else {"backend": args.backend, "ranks": dist.get_world_size(),
