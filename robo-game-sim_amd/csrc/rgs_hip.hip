@@ -15,6 +15,7 @@
 
 #include <cerrno>
 #include <fcntl.h>
+#include <sys/resource.h>
 #include <unistd.h>
 
 #include "../../include/rgs_hip.h"
@@ -1022,6 +1023,19 @@ int rgs_log_open(rgs_sim *s, int n_files, const int *arena_ids, const char *cons
     if (arena_ids[q] < 0 || arena_ids[q] >= s->B || !paths[q]) return fail(RGS_ERR_ARG, "rgs_log_open: arena id out of range or null path");
   int rc = rgs_log_close(s);                                   // like Logger::open: a log that is still open is closed first
   if (rc != RGS_OK) return rc;
+  {                                                            // every file stays open until rgs_log_close: mind the descriptor limit
+    struct rlimit lim;
+    if (getrlimit(RLIMIT_NOFILE, &lim) == 0 && lim.rlim_cur != RLIM_INFINITY && (rlim_t)n_files + 256 > lim.rlim_cur) {
+      const rlim_t want = (rlim_t)n_files + 256;
+      if (lim.rlim_max == RLIM_INFINITY || want <= lim.rlim_max) {
+        lim.rlim_cur = want;
+        (void)setrlimit(RLIMIT_NOFILE, &lim);                  // soft limit up to what is needed, inside the hard limit
+      } else {
+        return fail(RGS_ERR_UNSUPPORTED, "rgs_log_open: " + std::to_string(n_files) + " log files exceed the process's open-file limit (RLIMIT_NOFILE hard limit " +
+                                             std::to_string((unsigned long long)lim.rlim_max) + "); log fewer arenas per handle or raise the limit");
+      }
+    }
+  }
   HIP_TRY(hipSetDevice(s->device));
   s->log_fds.assign((size_t)n_files, -1);
   const int T = log_threads((size_t)n_files);

@@ -178,6 +178,22 @@ def test_library_written_log_files_equal_the_oracles(rgp, oracle, tmp_path, n, c
     sim.close()
 
 
+def test_log_open_reports_the_descriptor_limit(rgp, tmp_path):
+    """Every log file stays open until log_close: more files than the process may hold open is refused up front with a
+    message that says so (below the hard limit the soft limit is raised instead)."""
+    import resource
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    if hard == resource.RLIM_INFINITY or hard > 100000:
+        pytest.skip("no practical descriptor limit here")
+    B = hard + 10
+    sim = rgp.BatchedGameSim(B, 2)
+    with pytest.raises(rgp.RgsError) as e:
+        sim.log_open(list(range(B)), [str(tmp_path / ("f%d.log" % a)) for a in range(B)])
+    assert "open-file limit" in str(e.value)
+    assert not any(tmp_path.iterdir())                            # nothing was created
+    sim.close()
+
+
 @pytest.mark.parametrize("mode", ["host", "device"])
 def test_recorded_steps_with_noise(rgp, oracle, tmp_path, mode):
     """noise > 0 (host-tape wave kernel, one step per launch; device generator, fused launches): the in-kernel records
