@@ -97,6 +97,36 @@ def test_batched_monte_carlo_equals_sequential(rgp, oracle, tmp_path):
     assert out["scores"].sum() > 0 and (~out["undecided"]).any()       # some games were decided early
 
 
+def test_noisy_batched_monte_carlo_writes_the_reference_files(rgp, oracle, tmp_path):
+    """mc_example-style ensemble WITH noise (py/MonteCarlo.py:28-30 passes noise_stdev and seed = run number): all runs in
+    one batch, open-loop policy in fused chunks, files from the library's writer -- byte-identical to the oracle playing
+    each run alone with seed i (device generator where it is exact, host tapes otherwise)."""
+    from robo_game_py.montecarlo import monte_carlo_batched, mindless_policy, steps_per_run
+    p = Params(str(tmp_path / "noisy_mc"), num_runs=40, T=3.0)
+    p.noise_stdev = 0.3
+    p.winning_score = 1
+    p.x0_ball = np.array([3.5, 0.2, 6.0, 0.0])                     # shot towards the right goal: some runs end early
+    out = monte_carlo_batched(p, mindless_policy, chunk_steps=16)
+    N = steps_per_run(p)
+    ended = 0
+    for r in range(1, p.num_runs + 1):
+        s = oracle.OracleGameSim()
+        ref_log = str(tmp_path / ("o_%d.log" % r))
+        s.reset(p.dt, p.winning_score, p.x0_ball, p.noise_stdev, True, ref_log, r, p.tau_puck, p.tau_player, p.player_mass, p.puck_mass)
+        st = s.run(np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2))
+        t = 0.0
+        for k in range(N):
+            u = mindless_policy(st.reshape(22, 1), k, t, np.array([r]))
+            st = s.run(np.ascontiguousarray(u[:, :, 0]))
+            t += p.dt
+        s.reset(p.dt, p.winning_score, p.x0_ball)
+        want = open(ref_log, "rb").read()
+        assert open(os.path.join(p.log_prefix, "mc_run_%d.log" % r), "rb").read() == want, "run %d" % r
+        assert np.array_equal(out["state"][:, r - 1], st)
+        ended += len(want) < 29 * 8 * (N + 1)
+    assert 0 < ended                                               # games that were decided stop logging
+
+
 @pytest.mark.parametrize("variant,chunk", [(0, 64), (1, 64), (2, 64), (3, 64), (4, 64), (5, 64), (5, 7), (2, 1)])
 def test_recorded_steps_match_oracle_log_records(rgp, oracle, tmp_path, variant, chunk):
     """run_table_recorded returns exactly the reference's per-step record for every arena (4v4 too).  The records are
