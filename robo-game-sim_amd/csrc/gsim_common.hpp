@@ -281,8 +281,8 @@ __device__ __forceinline__ Chain rk4_axis(Chain x, double u, double coef, double
 // RK4_player with the noise term of f_player (cpp:62-88): xdot_v = (u - v)/tau + w_stdev * N(0,1), two
 // draws per f_player call in the order vx, vy, i.e. this axis' draw of stage s is nz[2*s].  The puck
 // passes sigma = 0 (f_puck draws nothing; adding +0.0 changes no value).  IEEE division.
-// DM != 0 (device-generator mode only, where parity is statistical): the division by tau through div_tau<DM>, which
-// equals the IEEE quotient whenever its magnitude window holds (always, outside underflow).
+// DM != 0 (device-generator kernel only): the division by tau through div_tau<DM>, which equals the IEEE quotient whenever
+// its magnitude window holds; the callers check the window per chain (rk4_noise_dyn / fast_division_safe, gsim_wave.hpp).
 template <int DM = 0>
 __device__ __forceinline__ Chain rk4_axis_noise(Chain x, double u, double coef, double tau, double h, double sigma,
                                                 const double *nz, double inv = 0.0) {

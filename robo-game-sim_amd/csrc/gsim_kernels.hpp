@@ -47,8 +47,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) GSIM_WAVE_OCCUPANCY void k_ste
 }
 
 // One wavefront per arena with the reference's noise generator ON THE DEVICE (gsim_rng.hpp): n_steps fused steps per
-// launch, any number of arenas; statistical parity with the reference (the exact mode is k_step_wave<.., NOISE = 1> fed
-// with host-drawn tapes).
+// launch, any number of arenas; bit-identical to the reference's draws where the host's log() could be restated
+// (GSIM_HOST_LOG, gsim_hostlog.hpp), statistical parity otherwise (k_step_wave<.., NOISE = 1> is fed with host-drawn tapes).
 #ifndef GSIM_RNG_WAVES
 #define GSIM_RNG_WAVES GSIM_WAVE_WAVES                       // wavefronts per SIMD of the device-noise kernel (0: the compiler's choice); measured at 2v2 / 3v3: 2 = 3 (+-1 %), 4 is 3 % slower
 #endif

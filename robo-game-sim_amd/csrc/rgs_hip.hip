@@ -660,8 +660,8 @@ int launch_steps(rgs_sim *s, const double *ctl_dev, long long stride, int n_step
   if (s->sigma != 0.0 && s->noise_mode == 1) {                 // noise from the device generator: fused launch, any batch size
     a.sigma = s->sigma;
     a.rng_x = s->rng_x; a.rng_left_n = s->rng_left_n; a.rng_left = s->rng_left;
-    // division by the taus as in the noise-free wave kernel (the reciprocal forms equal '/' inside their magnitude window; this
-    // mode is statistical anyway, rgs_set_fast_division(0) forces IEEE)
+    // division by the taus as in the noise-free wave kernel (the reciprocal forms equal '/' inside their magnitude window;
+    // rgs_set_fast_division(0) forces IEEE)
     // (with the host's log the draws are the reference's bit for bit, gsim_hostlog.hpp, so the division has to be exact as
     // well: the reciprocal forms only inside their window, which for a noisy player needs a sigma of ordinary size)
     const bool sigma_ok = std::fabs(s->sigma) >= 0x1p-300 && std::fabs(s->sigma) <= 0x1p300;
